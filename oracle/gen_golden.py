@@ -1,0 +1,348 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY; runs in the BUILD CONTAINER only.
+
+Generates tests/golden/*.npz by running the REFERENCE'S OWN Python
+(/root/reference/core/modeling/edge_snake/snake_head.py, .../dsnake_head.py; loaded by
+oracle/ref_loader.py) on seeded inputs.  A fixture is data only: inputs (or the seed that
+regenerates them through dance_amd/synthetic.py), the configuration, and the reference's
+outputs.  Weights and feature maps are never stored -- they are regenerated from the seed
+and guarded by a checksum kept in the fixture.
+
+    python -m oracle.gen_golden            # from the repo root, in the build container
+
+The script also cross-checks oracle/snake_ref.py and the C resampler against the
+reference on every case and fails if they disagree (ints bit-exact, floats 1e-5).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from dance_amd import synthetic
+from oracle import extreme_utils_ref, ref_loader, snake_ref
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+WEIGHT_SEED = 1234
+
+
+def _save(name, **arrays):
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print("wrote %-28s %7.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def _close(a, b, tol=1e-5, what=""):
+    # NaNs are part of the reference's behaviour (derange divides by max-min with no
+    # epsilon, snake_head.py:1588-1593): they must sit at the same places.
+    assert torch.equal(torch.isnan(a), torch.isnan(b)), what + ": NaN pattern differs"
+    a, b = torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0)
+    err = float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) if a.numel() else 0.0
+    assert err <= tol, "%s: oracle vs reference rel err %.3g" % (what, err)
+    return err
+
+
+# ------------------------------------------------------------------------------- G1
+def resampler_polygons():
+    g = torch.Generator().manual_seed(7)
+    cases = {}
+    # random float boxes (the DANCE initial contour, snake_head.py:911-924)
+    boxes = synthetic.make_boxes(40, 800, 1216, seed=11)
+    cases["box"] = snake_ref.box_polygon(boxes)
+    # integer boxes: many exact .5 ties in len*p/sum, degenerate and sliver boxes
+    ib = torch.tensor([[0, 0, 1, 127], [10, 10, 74, 74], [5, 5, 5, 5], [3, 9, 3, 200],
+                       [0, 0, 1215, 799], [100, 50, 103, 51], [7, 7, 8, 8], [20, 30, 220, 31],
+                       [1, 2, 4, 130], [50, 60, 51, 60.001]], dtype=torch.float32)
+    cases["box_int"] = snake_ref.box_polygon(ib)
+    # quadrangles (Dsnake initial contour, dsnake_head.py:501-517)
+    cases["quad"] = snake_ref.quadrangle(boxes[:20])
+    # octagons from extreme points (snake_head.py:796-832): random + collapsed ones
+    cx, cy = (boxes[:30, 0] + boxes[:30, 2]) / 2, (boxes[:30, 1] + boxes[:30, 3]) / 2
+    w, h = boxes[:30, 2] - boxes[:30, 0], boxes[:30, 3] - boxes[:30, 1]
+    j = (torch.rand((30, 4), generator=g) - 0.5)
+    ex = torch.stack([cx + j[:, 0] * w, boxes[:30, 1], boxes[:30, 0], cy + j[:, 1] * h,
+                      cx + j[:, 2] * w, boxes[:30, 3], boxes[:30, 2], cy + j[:, 3] * h],
+                     dim=1).view(-1, 4, 2)
+    ex[3] = ex[3, 0]                  # all four extreme points identical
+    ex[4, :, 1] = ex[4, 0, 1]         # zero height
+    ex[5, 0, 0] = ex[5, 1, 0]         # top point in the left corner
+    cases["octagon"] = snake_ref.octagon_polygon(ex)
+    cases["octagon_ext"] = ex
+    # random 12-gons and 7-gons far from any structure
+    cases["ngon12"] = torch.rand((25, 12, 2), generator=g) * 300
+    cases["ngon7"] = torch.rand((10, 7, 2), generator=g) * 50
+    return cases
+
+
+def gen_resampler(sh):
+    polys = resampler_polygons()
+    out = {}
+    for name, p_nums in (("box", (128, 196, 256)), ("box_int", (128, 196)), ("quad", (40,)),
+                         ("octagon", (128, 196)), ("ngon12", (128, 40)), ("ngon7", (128,))):
+        poly = polys[name].clone()
+        out[name + "_poly"] = poly
+        for p in p_nums:
+            pts, start = sh.RefineNet.uniform_upsample(poly.clone()[None], p)
+            out["%s_p%d_points" % (name, p)] = pts
+            out["%s_p%d_start" % (name, p)] = start
+            o_pts, o_start = snake_ref.uniform_upsample(poly.clone()[None], p)
+            assert torch.equal(o_start, start), (name, p)
+            assert torch.equal(o_pts, pts), (name, p)
+            c_pts, c_start, c_status = extreme_utils_ref.uniform_upsample_fused(poly, p)
+            assert int(c_status.sum()) == 0
+            assert torch.equal(c_start, start), ("C resampler start", name, p)
+            assert torch.equal(c_pts, pts), ("C resampler points", name, p,
+                                            float((c_pts - pts).abs().max()))
+    # get_octagon straight from extreme points (reference method, needs an instance)
+    ex = polys["octagon_ext"]
+    net = sh.RefineNet(ref_loader.dance_cfg(num_convs=0))
+    pts, start = net.get_octagon(ex.clone(), 128)
+    assert torch.equal(pts, out["octagon_p128_points"])
+    out["octagon_ext"] = ex
+    # NumPy twin of the resampler (snake_head.py:661-725): non-authoritative cross-check
+    agree = 0
+    for i in range(polys["ngon12"].size(0)):
+        tw = sh.RefineNet.uniform_sample(polys["ngon12"][i].numpy(), 128)
+        agree += int(np.abs(tw - out["ngon12_p128_points"][i].numpy()).max() < 1e-3)
+    print("numpy twin uniform_sample agrees on %d/%d random 12-gons" % (agree, polys["ngon12"].size(0)))
+    _save("g1_resampler", **out)
+
+
+# ------------------------------------------------------------------------------- G2
+def gen_gather(sh, dh):
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn((2, 5, 7, 9), generator=g)
+    H, W = 28, 36
+    n, v = 6, 16
+    loc = torch.rand((n, v, 2), generator=g) * torch.tensor([W, H]) * 1.6 - torch.tensor([W, H]) * 0.3
+    # exact pixel centres, borders and far outside points
+    loc[0, :8] = torch.tensor([[2.0, 2.0], [0.0, 0.0], [W - 1.0, H - 1.0], [W, H], [-0.5, 5.0],
+                               [6.0, 6.0], [-40.0, 90.0], [35.999, 27.999]])
+    idx = torch.tensor([0, 1, 1, 0, 1, 0], dtype=torch.float32)
+    net = sh.RefineNet(ref_loader.dance_cfg(num_convs=0, convs_dim=4))
+    dnet = dh.DsnakeHead(ref_loader.dsnake_cfg(num_convs=0, convs_dim=4))
+    refl_b = net.get_locations_feature(feats, loc, idx)
+    refl_1 = net.get_locations_feature(feats[:1], loc, None)
+    zero_b = dnet.get_locations_feature(feats, loc, idx)
+    for a, b, mode, fi, ii in ((refl_b, None, "reflection", feats, idx),
+                               (refl_1, None, "reflection", feats[:1], None),
+                               (zero_b, None, "zeros", feats, idx)):
+        o = snake_ref.get_locations_feature(fi, loc, ii, mode)
+        assert torch.equal(o, a)
+    # closed form vs grid_sample
+    for i in range(n):
+        cf = snake_ref.bilinear_sample_closed_form(feats[int(idx[i])], loc[i], "reflection")
+        _close(cf, refl_b[i], 1e-5, "closed-form reflection")
+        cf = snake_ref.bilinear_sample_closed_form(feats[int(idx[i])], loc[i], "zeros")
+        _close(cf, zero_b[i], 1e-5, "closed-form zeros")
+    _save("g2_gather", features=feats, locations=loc, image_idx=idx,
+          reflection_batched=refl_b, reflection_single=refl_1, zeros_batched=zero_b)
+
+
+# --------------------------------------------------------------------------- G3 / G4
+def gen_blocks(sh):
+    out = {}
+    g = torch.Generator().manual_seed(33)
+    for tag, cin, d, v in (("c128_d1_v128", 128, 1, 128), ("c128_d2_v196", 128, 2, 196),
+                           ("c128_d4_v40", 128, 4, 40), ("c258_d1_v128", 258, 1, 128),
+                           ("c128_d4_v256", 128, 4, 256)):
+        blk = sh.SnakeBlock(cin, 128, n_adj=4, dilation=d).eval()
+        sd = blk.state_dict()
+        ck = synthetic.fill_state_dict_(sd, WEIGHT_SEED + d + v)
+        x = torch.randn((2, cin, v), generator=g)
+        with torch.no_grad():
+            y = blk(x)
+            o = snake_ref.snake_block(x, sd, "", d)
+        _close(o, y, 1e-6, "snake_block " + tag)
+        out[tag + "_x"] = x
+        out[tag + "_y"] = y
+        out[tag + "_checksum"] = ck
+        out[tag + "_seed"] = WEIGHT_SEED + d + v
+    _save("g3_snake_block", **out)
+
+
+def gen_snakenet(sh):
+    out = {}
+    g = torch.Generator().manual_seed(44)
+    cfg = ref_loader.dance_cfg()
+    for tag, v in (("v128", 128), ("v196", 196), ("v40", 40)):
+        net = sh._SnakeNet(cfg, 0).eval()
+        sd = net.state_dict()
+        ck = synthetic.fill_state_dict_(sd, WEIGHT_SEED + v)
+        x = torch.randn((3, 258, v), generator=g)
+        x[:, 256:] = torch.rand((3, 2, v), generator=g)
+        with torch.no_grad():
+            y = net(x)
+            o, state = snake_ref.snake_net(x, sd, return_states=True)
+        _close(o, y, 1e-5, "snake_net " + tag)
+        out[tag + "_x"] = x
+        out[tag + "_y"] = y
+        out[tag + "_state_l2"] = state.pow(2).sum(dim=2).sqrt()     # (3,1024) per-channel norms
+        out[tag + "_checksum"] = ck
+        out[tag + "_seed"] = WEIGHT_SEED + v
+    _save("g4_snake_net", **out)
+
+
+# ------------------------------------------------------------------------------- G5
+def _dance_case(sh, tag, *, num_sampling, initial, batch, n_per_im, attention=True,
+                individual_scale=True, de_loc_type="derange", feat_seed, box_seed, hf=50, wf=76):
+    cfg = ref_loader.dance_cfg(num_sampling=num_sampling, initial=initial, num_convs=0,
+                               attention=attention, individual_scale=individual_scale,
+                               de_loc_type=de_loc_type)
+    net = sh.RefineNet(cfg).eval()
+    sd = net.state_dict()
+    ck = synthetic.fill_state_dict_(sd, WEIGHT_SEED)
+    H, W = hf * 4, wf * 4
+    feats = synthetic.make_features(batch, 256, hf, wf, feat_seed, attention=attention)
+    boxes, insts = [], []
+    for i in range(batch):
+        b = synthetic.make_boxes(n_per_im, H, W, box_seed + i, r_min=8.0, r_max=60.0)
+        if i == 0:
+            b[0] = torch.tensor([W - 70.0, H - 50.0, W - 1.0, H - 1.0])   # hugs the corner
+        boxes.append(b)
+        fields = dict(pred_boxes=ref_loader.FakeBoxes(b.clone()))
+        if initial == "octagon":
+            g = torch.Generator().manual_seed(box_seed + 100 + i)
+            j = torch.rand((n_per_im, 4), generator=g)
+            w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+            ex = torch.stack([b[:, 0] + j[:, 0] * w, b[:, 1], b[:, 0], b[:, 1] + j[:, 1] * h,
+                              b[:, 0] + j[:, 2] * w, b[:, 3], b[:, 2], b[:, 1] + j[:, 3] * h],
+                             dim=1).view(-1, 4, 2)
+            ex[1, 0, 0] -= 30.0      # outside its box: fit_to_box must pull it back
+            fields["ext_points"] = _Ext(ex.clone())
+            fields["_ext_in"] = ex
+        insts.append(ref_loader.FakeInstances((H, W), **fields))
+    with torch.no_grad():
+        if batch == 1:
+            # single-image path, snake_head.py:1763-1869
+            if initial == "octagon":
+                locations, image_idx = net.sample_octagons_fast(insts)
+                image_idx = None
+            else:
+                locations, image_idx = net.single_sample_bboxes_fast(insts)
+            image_sizes = insts[0].image_size
+            insts[0].pred_boxes.clip(image_sizes)
+            bb = insts[0].pred_boxes.tensor
+        else:
+            # batched path, snake_head.py:1895-1941
+            if initial == "octagon":
+                locations, image_idx = net.sample_octagons_fast(insts)
+            else:
+                locations, image_idx = net.sample_bboxes_fast(insts)
+            image_sizes = [x.image_size for x in insts]
+            bb = torch.cat([x.pred_boxes.tensor for x in insts], dim=0)
+        whs = torch.stack([bb[:, 2] - bb[:, 0], bb[:, 3] - bb[:, 1]], dim=1)
+        preds, cur = [], locations
+        for i in range(3):
+            cur, _ = net.evolve(getattr(net, "deformer%d" % i), feats, cur, image_idx,
+                                image_sizes, whs, att=(attention and i > 0))
+            preds.append(cur)
+        o_preds = snake_ref.dance_deform(sd, feats, locations, image_idx, image_sizes, whs,
+                                         attention=attention, individual_scale=individual_scale,
+                                         de_loc_type=de_loc_type)
+        if batch == 1 and initial == "box":
+            # whole reference forward (eval): must reproduce the last iteration
+            insts2 = [ref_loader.FakeInstances((H, W), pred_boxes=ref_loader.FakeBoxes(boxes[0].clone()))]
+            res, _ = net(feats, insts2, None)
+            assert torch.equal(res[0].pred_polys.tensor, preds[-1])
+    for a, b in zip(o_preds, preds):
+        _close(a, b, 1e-5, "dance_deform " + tag)
+    out = dict(boxes=torch.stack(boxes), init=locations, whs=whs,
+               image_idx=(torch.zeros(0) if image_idx is None else image_idx),
+               pred0=preds[0], pred1=preds[1], pred2=preds[2], checksum=ck,
+               feat_seed=feat_seed, weight_seed=WEIGHT_SEED, hf=hf, wf=wf, batch=batch,
+               num_sampling=num_sampling, attention=int(attention),
+               individual_scale=int(individual_scale))
+    if initial == "octagon":
+        out["ext_points"] = torch.stack([x._ext_in for x in insts])
+    _save("g5_dance_" + tag, **out)
+    return out
+
+
+class _Ext:
+    """ExtremePoints duck type with the reference's fit_to_box (pointset.py:132-142),
+    restated in oracle.snake_ref.fit_to_box."""
+
+    def __init__(self, t):
+        self.tensor = t
+
+    def fit_to_box(self):
+        snake_ref.fit_to_box(self.tensor)
+
+
+def gen_dance(sh):
+    _dance_case(sh, "single_box_v196", num_sampling=196, initial="box", batch=1, n_per_im=5,
+                feat_seed=501, box_seed=601)
+    _dance_case(sh, "batched_box_v128", num_sampling=128, initial="box", batch=2, n_per_im=3,
+                feat_seed=502, box_seed=602)
+    _dance_case(sh, "single_octagon_v128", num_sampling=128, initial="octagon", batch=1,
+                n_per_im=4, feat_seed=503, box_seed=603)
+    _dance_case(sh, "plain_demean_v128", num_sampling=128, initial="box", batch=2, n_per_im=2,
+                attention=False, individual_scale=False, de_loc_type="demean",
+                feat_seed=504, box_seed=604)
+
+
+# ------------------------------------------------------------------------------- G6
+def gen_dsnake(dh):
+    cfg = ref_loader.dsnake_cfg(num_convs=0)
+    net = dh.DsnakeHead(cfg).eval()
+    sd = net.state_dict()
+    ck = synthetic.fill_state_dict_(sd, WEIGHT_SEED)
+    hf, wf, batch, n_per_im = 50, 76, 2, 3
+    H, W = hf * 4, wf * 4
+    feats = synthetic.make_features(batch, 256, hf, wf, 701, attention=False)
+    boxes = [synthetic.make_boxes(n_per_im, H, W, 801 + i, r_min=8.0, r_max=60.0) for i in range(batch)]
+    insts = [ref_loader.FakeInstances((H, W), pred_boxes=ref_loader.FakeBoxes(b.clone())) for b in boxes]
+    with torch.no_grad():
+        res, _ = net(feats, insts, None)
+        o = snake_ref.dsnake_deform(sd, feats, boxes)
+    final = torch.cat([r.pred_polys.tensor for r in res])
+    exts = torch.cat([r.ext_points.tensor for r in res])
+    _close(o["preds"][-1], final, 1e-5, "dsnake final")
+    _close(o["exts"], exts, 1e-5, "dsnake exts")
+    # per-stage values through the reference's own methods (dsnake_head.py:783-830)
+    with torch.no_grad():
+        init, image_idx = net.sample_quadrangles_fast(insts)
+        pe = net.init(net.init_snake, feats, init, image_idx)
+        octs = []
+        for i in range(batch):
+            e = pe[image_idx == i]
+            e[..., 0] = torch.clamp(e[..., 0], min=0, max=W - 1)
+            e[..., 1] = torch.clamp(e[..., 1], min=0, max=H - 1)
+            octs.append(net.get_octagon(e, 128))
+        octs = torch.cat(octs)
+        preds, cur = [], octs
+        for i in range(3):
+            cur = net.evolve(getattr(net, "deformer%d" % i), feats, cur, image_idx)
+            preds.append(cur)
+    assert torch.equal(preds[-1], final)
+    assert torch.equal(init, o["init"])
+    _close(o["octagons"], octs, 1e-5, "dsnake octagons")
+    for a, b in zip(o["preds"], preds):
+        _close(a, b, 1e-5, "dsnake preds")
+    _save("g6_dsnake", boxes=torch.stack(boxes), init=init, image_idx=image_idx, exts_raw=pe,
+          exts=exts, octagons=octs, pred0=preds[0], pred1=preds[1], pred2=preds[2],
+          checksum=ck, feat_seed=701, weight_seed=WEIGHT_SEED, hf=hf, wf=wf)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_flush_denormal(False)
+    extreme_utils_ref.build()
+    sh, dh = ref_loader.load_reference()
+    gen_resampler(sh)
+    gen_gather(sh, dh)
+    gen_blocks(sh)
+    gen_snakenet(sh)
+    gen_dance(sh)
+    gen_dsnake(dh)
+    print("golden vectors written to", os.path.normpath(OUT))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,179 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY; runs in the BUILD CONTAINER only.
+
+Loads the reference's Python snake heads straight from /root/reference (read-only, never
+copied) so that oracle/gen_golden.py can produce golden vectors with the reference's own
+code.  Third-party packages the reference imports but this image lacks (detectron2,
+pycocotools, shapely, fvcore) are satisfied with minimal import-time placeholders; the
+reference's `core.layers.extreme_utils` (an unbuildable CUDA extension) is satisfied by
+the C restatement in oracle/extreme_utils_ref.c -- which is exactly how that restatement
+gets pinned: the reference's `uniform_upsample` drives it.
+
+Nothing here is importable on the GPU box (/root/reference does not exist there).
+"""
+import importlib.util
+import sys
+import types
+from types import SimpleNamespace as NS
+
+import torch
+import torch.nn as nn
+
+from . import extreme_utils_ref
+
+REF = "/root/reference"
+
+
+class _Conv2d(nn.Conv2d):
+    """Signature-compatible stand-in for detectron2.layers.Conv2d (norm=, activation=)."""
+
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = super().forward(x)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def _cat(tensors, dim=0):
+    if len(tensors) == 1:
+        return tensors[0]
+    return torch.cat(tensors, dim)
+
+
+class _Dummy(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+class _TensorBox:
+    """Placeholder for core.structures.{ExtremePoints,PolygonPoints}: holds `.tensor`."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
+class _SmoothL1:
+    def __init__(self, beta=0.11):
+        self.beta = beta
+
+
+def _module(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_loaded = {}
+
+
+def load_reference():
+    """Returns (snake_head_module, dsnake_head_module) loaded from /root/reference."""
+    if _loaded:
+        return _loaded["snake"], _loaded["dsnake"]
+    _module("detectron2")
+    _module("detectron2.layers", Conv2d=_Conv2d, DeformConv=_Dummy, ModulatedDeformConv=_Dummy,
+            cat=_cat, ShapeSpec=NS)
+    _module("pycocotools")
+    _module("pycocotools.mask")
+    _module("shapely")
+    _module("shapely.geometry", Polygon=object)
+    _module("fvcore")
+    _module("fvcore.nn")
+    _module("fvcore.nn.weight_init")
+    timer = _load("_dance_ref_timer", REF + "/core/utils/timer.py")
+    _module("core")
+    _module("core.layers", DFConv2d=_Dummy, SmoothL1Loss=_SmoothL1,
+            extreme_utils=extreme_utils_ref)
+    _module("core.modeling")
+    _module("core.modeling.fcose")
+    _module("core.modeling.fcose.utils", get_aux_extreme_points=None, get_extreme_points=None)
+    _module("core.structures", ExtremePoints=_TensorBox, PolygonPoints=_TensorBox)
+    _module("core.utils", timer=timer)
+    _loaded["snake"] = _load("_dance_ref_snake_head",
+                             REF + "/core/modeling/edge_snake/snake_head.py")
+    _loaded["dsnake"] = _load("_dance_ref_dsnake_head",
+                              REF + "/core/modeling/dsnake_baseline/dsnake_head.py")
+    return _loaded["snake"], _loaded["dsnake"]
+
+
+def dance_cfg(num_sampling=196, initial="box", num_convs=2, attention=True,
+              individual_scale=True, de_loc_type="derange", convs_dim=256):
+    """configs/Dance_R_50_3x.yaml on top of core/config/defaults.py -- only the keys
+    RefineNet.__init__ (snake_head.py:434-542) and _SnakeNet (220-258) read."""
+    snake = NS(
+        DETACH=True, ORIGINAL=False, STRUCTURE="sequential", CONV_TYPE="ccn", FEAT_DIM=128,
+        NUM_ITER=(0, 0, 1), NUM_CONVS=num_convs, STRONGER=False, MULTI_OFFSET=1, SKIP=False,
+        NUM_LAYER=(8, 8, 8), CIR_DILATIONS=((1, 1, 1, 2, 2, 4, 4),) * 3,
+        MSCORE_SNAKE_ON=False, PRE_OFFSET=False, USE_ASPP=False, USE_PSP=False,
+        LAST_UP_SAMPLE=False, UP_SAMPLE_RATE=2, LAST_CHAMFER=False, LAST_NEIGHBOR=False,
+        TRACK_PATH=False, NEW_MATCHING=True, INITIAL=initial, DE_LOC_TYPE=de_loc_type,
+        INDIVIDUAL_SCALE=individual_scale, LOSS_TYPE="smoothl1", LOSS_ADAPTIVE=False,
+        LOSS_SEPARATE_REFINE=False, LOSS_WEIGH=False, LOSS_DISTRIBUTION=(1 / 3, 1 / 3, 2 / 3),
+        LOSS_L1_BETA=0.11, EDGE_IN=False, PRED_EDGE=False, EDGE_IN_SEPARATE=(False, False),
+        DILATIONS=(1, 1), COORD_CONV=(False, False), FILTER_WIDTH=4,
+        USE_DEFORMABLE=(False, False), NUM_SAMPLING=num_sampling, MARK_INDEX=False,
+        REORDER_METHOD="dsnake", JITTERING=0.0, POINT_WEIGH=False, ATTENTION=attention,
+        SELECTIVE_REFINE=False, DOUBLE_SELECTIVE_REFINE=False, VIS_PATH=False,
+    )
+    return NS(MODEL=NS(EDGE_HEAD=NS(CONVS_DIM=convs_dim, NORM="GN"),
+                       DEFORM_HEAD=NS(NUM_CONVS=256), SNAKE_HEAD=snake))
+
+
+def dsnake_cfg(num_sampling=128, num_convs=2, convs_dim=256):
+    """configs/Dsnake_R_50_1x.yaml on defaults.py -- keys DsnakeHead.__init__ reads
+    (dsnake_head.py:198-259)."""
+    snake = NS(CONV_TYPE="ccn", INITIAL="octagon", FILTER_WIDTH=4, NUM_ITER=(0, 0, 1),
+               NUM_CONVS=num_convs, NUM_SAMPLING=num_sampling, DE_LOC_TYPE="derange",
+               DILATIONS=(1, 1), REORDER_METHOD="dsnake", VIS_PATH=False,
+               LOSS_TYPE="smoothl1", LOSS_L1_BETA=0.11)
+    return NS(MODEL=NS(EDGE_HEAD=NS(CONVS_DIM=convs_dim, NORM="GN"), SNAKE_HEAD=snake))
+
+
+class FakeBoxes:
+    """Duck-typed detectron2 Boxes: `.tensor`, `.clip(image_size)` (in place)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    def clip(self, box_size):
+        h, w = box_size
+        self.tensor[:, 0].clamp_(min=0, max=w)
+        self.tensor[:, 1].clamp_(min=0, max=h)
+        self.tensor[:, 2].clamp_(min=0, max=w)
+        self.tensor[:, 3].clamp_(min=0, max=h)
+
+
+class FakeInstances:
+    """Duck-typed detectron2 Instances carrying only what the snake heads touch."""
+
+    def __init__(self, image_size, **fields):
+        self.image_size = image_size
+        self._fields = set()
+        for k, v in fields.items():
+            setattr(self, k, v)
+
+    def __setattr__(self, k, v):
+        if not k.startswith("_") and k != "image_size":
+            self._fields.add(k)
+        object.__setattr__(self, k, v)
+
+    def has(self, name):
+        return name in self._fields
