@@ -1,0 +1,215 @@
+"""Benchmark of the contour-deformation hot path (BASELINE.json metric: contours deformed/sec,
+128 vertices, all iterations; gather HBM GB/s).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (per GPU, weak scaling): BASELINE config 2 -- DANCE R50 snake head, fp32,
+16 images x 100 instances x 128 vertices on synthetic 800x1216 FPN features
+(16, 1+256, 200, 304), attention + individual scale on, 3 deformation iterations.
+One step = the reference's `snake_deformation` scope (snake_head.py:1822-1862) over that
+batch, starting from the NCHW (attention + features) tensor resident in HBM: layout pass,
+3 x (fused gather + head block, 7 residual blocks, fusion + max, prediction, offset
+update) and, for N > 1, the RCCL all-gather of the deformed contours.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+IMAGES, PER_IMAGE, VERTS, CH, HF, WF, ITERS = 16, 100, 128, 256, 200, 304, 3
+# MACs per vertex per iteration of one _SnakeNet (C = 256)
+MACS_RES_BLOCK = 128 * 128 * 9
+MACS_PER_VERTEX = (CH + 2) * 128 * 9 + 7 * MACS_RES_BLOCK + 1024 * 256 + 1280 * 256 + 256 * 64 + 64 * 2
+GATHER_BYTES_PER_VERTEX = 4 * (CH + 1) * 4            # 4 taps x 257 channels x fp32
+PEAK_F32_MFMA_TFLOPS = 157.3                          # MI355X_MICROARCH.md, f32-input MFMA
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", type=int, default=IMAGES, help="images per GPU")
+    ap.add_argument("--per-image", type=int, default=PER_IMAGE)
+    ap.add_argument("--vertices", type=int, default=VERTS)
+    ap.add_argument("--layout", choices=("nchw", "nhwc"), default="nchw",
+                    help="nchw (default): the layout pass is inside the timed step")
+    ap.add_argument("--no-fused-head", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(reps):
+    """The oracle (torch-CPU restatement of the reference path, parity-pinned by
+    tests/golden) on BASELINE config 1: 1 image, 100 instances x 128 vertices, 3 iterations."""
+    from dance_amd import config, modules, synthetic
+    from oracle import snake_ref
+
+    torch.set_flush_denormal(True)
+    cfg = config.dance_r50(num_sampling=VERTS, num_convs=0)
+    sd = {k: v.clone() for k, v in modules.RefineNet(cfg).state_dict().items()}
+    synthetic.fill_state_dict_(sd, 1234)
+    feats = synthetic.make_features(1, CH, HF, WF, 1234)
+    boxes = synthetic.make_boxes(100, HF * 4, WF * 4, 4321)
+    init, _ = snake_ref.uniform_upsample(snake_ref.box_polygon(boxes)[None], VERTS)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
+    times = []
+    with torch.no_grad():
+        for r in range(reps + 1):
+            t0 = time.perf_counter()
+            snake_ref.dance_deform(sd, feats, init, None, (HF * 4, WF * 4), whs)
+            if r:
+                times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 100.0 / med, "unit": "contours/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "BASELINE config 1: 1 image (1,257,200,304), 100 contours x 128 vertices x 3 "
+                      "iterations; oracle/snake_ref.py, median of %d runs after 1 warm-up, "
+                      "flush_denormal on" % reps,
+            "seconds_per_run": med}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from dance_amd import config, modules, ops, snake, synthetic
+    from dance_amd._lib import EVOLVE_EVENTS, STAGE_NAMES
+    from dance_amd.distributed import all_gather_contours
+
+    b, per, v = args.images, args.per_image, args.vertices
+    n = b * per
+    h, w = HF * 4, WF * 4
+    cfg = config.dance_r50(num_sampling=v, num_convs=0)
+    sd = {k: t.clone() for k, t in modules.RefineNet(cfg).state_dict().items()}
+    synthetic.fill_state_dict_(sd, 1234)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), dev) for i in range(ITERS)]
+    deformer = snake.ContourDeformer(nets, fused_head=not args.no_fused_head)
+    deformer.MAX_CHUNK = max(deformer.MAX_CHUNK, n)          # one kernel sequence per iteration
+
+    # synthetic inputs, resident in HBM before the timed region
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    feats = torch.empty((b, CH + 1, HF, WF), dtype=torch.float32, device=dev)
+    for i in range(b):                                       # per image: bounds host memory
+        feats[i] = synthetic.make_features(1, CH, HF, WF, 1234 + 1000 * rank + i)[0].to(dev)
+    boxes = synthetic.make_boxes(n, h, w, 4321 + rank)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).to(dev)
+    init, _ = ops.uniform_upsample(boxes.to(dev), v, kind=ops.POLY_BOX)
+    image_idx = torch.arange(b).repeat_interleave(per).float().to(dev)
+    sizes = [(h, w)] * b
+    del g
+
+    events = [[[torch.cuda.Event(enable_timing=True) for _ in range(EVOLVE_EVENTS)]
+               for _ in range(ITERS)] for _ in range(args.steps)]
+    for step_ev in events:
+        for it_ev in step_ev:
+            for e in it_ev:
+                e.record()                                   # creates the handle
+    layout_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                 for _ in range(args.steps)]
+    pre = deformer.prepare_features(feats) if args.layout == "nhwc" else None
+
+    def step(ev=None, lev=None):
+        if pre is None:
+            if lev:
+                lev[0].record()
+            f = deformer.prepare_features(feats)
+            if lev:
+                lev[1].record()
+        else:
+            f = pre
+        preds = deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", stage_events=ev)
+        return all_gather_contours(preds[-1])
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(events[k], layout_ev[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape == (world * n, v, 2) and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        # per-stage device time from the HIP events recorded inside the timed steps
+        stage_ms = [0.0] * len(STAGE_NAMES)
+        for k in range(args.steps):
+            for it in range(ITERS):
+                ev = events[k][it]
+                for s in range(len(STAGE_NAMES)):
+                    stage_ms[s] += ev[s].elapsed_time(ev[s + 1])
+        launches = args.steps * ITERS
+        stage_avg = {name: stage_ms[i] / launches for i, name in enumerate(STAGE_NAMES)}
+        res_ms = sum(stage_avg["res%d" % i] for i in range(7)) / 7.0       # one k_circconv launch
+        res_flops = 2.0 * MACS_RES_BLOCK * v * n
+        head_ms = stage_avg["head"]
+        gather_gbps = GATHER_BYTES_PER_VERTEX * v * n / (head_ms * 1e-3) / 1e9
+        layout_ms = (sum(a.elapsed_time(b_) for a, b_ in layout_ev) / args.steps) if pre is None else 0.0
+        ms_per_step = elapsed / args.steps * 1e3
+        total_flops = 2.0 * MACS_PER_VERTEX * v * n * ITERS
+        line = {
+            "metric": "contours deformed/sec (128 vertices, all iters)",
+            "value": world * n * args.steps / elapsed,
+            "unit": "contours/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: DANCE R50 snake head fp32, %d images x %d "
+                                   "instances x %d vertices per GPU, %d iterations, features "
+                                   "(%d,%d,%d,%d) %s in HBM" % (b, per, v, ITERS, b, CH + 1, HF, WF,
+                                                                args.layout.upper()),
+                       "contours_per_gpu": n, "vertices": v, "iterations": ITERS,
+                       "fused_head": not args.no_fused_head, "parallelism": "dp%d" % world},
+            "roofline": {"kernel": "k_circconv<4> (residual SnakeBlock 128->128, k=9)",
+                         "bound": "mfma", "achieved": res_flops / (res_ms * 1e-3) / 1e12,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": res_flops / (res_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": res_ms},
+            "gather": {"kernel": "k_gather_head<4> (fused gather + head SnakeBlock)",
+                       "algorithmic_GBps": gather_gbps, "frac_of_hbm_peak": gather_gbps / PEAK_HBM_GBPS,
+                       "avg_launch_ms": head_ms,
+                       "note": "fused kernel is MFMA-bound in fp32 (76 MFLOP per 526 KB contour-iteration)"},
+            "whole_path_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
+            "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_reps)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

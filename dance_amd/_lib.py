@@ -1,0 +1,103 @@
+"""ctypes binding of libdance_hip.so (C ABI: include/dance_hip.h).
+
+There is NO fallback: if the shared object is missing or a symbol is absent, importing
+`lib()` raises.  The product path never routes through torch ops or the oracle.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdance_hip.so")
+
+ABI_VERSION = 1
+EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
+STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
+               "row_constant", "pred0", "pred1", "offset_update")
+
+
+class SnakeNetStruct(ctypes.Structure):
+    """Mirror of `dance_snake_net` (include/dance_hip.h)."""
+
+    _fields_ = [
+        ("head_w", c_void_p), ("head_b", c_void_p), ("head_scale", c_void_p), ("head_shift", c_void_p),
+        ("res_w", c_void_p * 7), ("res_b", c_void_p * 7), ("res_scale", c_void_p * 7),
+        ("res_shift", c_void_p * 7),
+        ("fusion_w", c_void_p), ("fusion_b", c_void_p),
+        ("pred0_wg", c_void_p),
+        ("pred0_ws", c_void_p), ("pred0_b", c_void_p),
+        ("pred1_w", c_void_p), ("pred1_b", c_void_p),
+        ("pred2_w", c_void_p), ("pred2_b", c_void_p),
+        ("dilation", c_int * 7),
+        ("feat_channels", c_int),
+    ]
+
+
+P = c_void_p
+# name -> (restype, argtypes); every symbol include/dance_hip.h declares
+SIGNATURES = {
+    "dance_abi_version": (c_int, []),
+    "dance_last_error": (c_char_p, []),
+    "dance_device_info": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "dance_collect_extreme_point": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_calculate_edge_num": (c_int, [P, P, P, c_int, c_int, c_int, c_int64, P]),
+    "dance_calculate_wnp": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_roll_array": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "dance_uniform_upsample": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P]),
+    "dance_nchw_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_gather_features": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, P]),
+    "dance_circconv": (c_int, [P, c_int64, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_int, P]),
+    "dance_gather_circconv_head": (c_int, [P, P, P, P, P, P, P, P, P, c_int64, P, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_row_constant": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "dance_offset_update": (c_int, [P, c_int64, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float,
+                                    c_float, P]),
+    "dance_snake_workspace_bytes": (c_int64, [c_int, c_int]),
+    "dance_snake_evolve": (c_int, [POINTER(SnakeNetStruct), P, P, P, P, P, P, P, P, c_int64, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_float, c_float, c_int, POINTER(c_void_p), P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "dance_amd: %s is missing -- build it with `python -m dance_amd.build` "
+            "(there is no CPU or torch fallback for the contour path)" % SO_PATH)
+    h = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(h, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = h.dance_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("dance_amd: libdance_hip.so ABI %d, bindings expect %d" % (got, ABI_VERSION))
+    _lib = h
+    return h
+
+
+def check(code, what):
+    """Turn a non-zero return code into RuntimeError (the reference's AT_ASSERTM /
+    THCudaCheck failures surface as RuntimeError too, utils.cu:162-209)."""
+    if code != 0:
+        msg = lib().dance_last_error()
+        raise RuntimeError("%s failed (hipError %d): %s" % (what, code, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

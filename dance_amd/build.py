@@ -1,0 +1,63 @@
+"""Builds libdance_hip.so in-tree with plain hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m dance_amd.build [--force] [--asm]
+
+The shared object sits next to this package (dance_amd/libdance_hip.so); it is git-ignored
+but travels with the tree to the GPU box.  No torch / pybind headers are involved: the
+library is a plain C ABI (include/dance_hip.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libdance_hip.so")
+OBJ = os.path.join(HERE, "_obj")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math"]
+# (source, extra flags).  The "exact" files round every fp32 op separately so that indices
+# and resampled coordinates are bit-identical to the reference's op sequence.
+SOURCES = [
+    ("exact_ops.hip", ["-ffp-contract=off"]),
+    ("gather.hip", []),
+    ("snake_mfma.hip", []),
+]
+HEADERS = ["common.h", "sampling.h", os.path.join("..", "..", "include", "dance_hip.h")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, keep_asm=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            cmd = [hipcc, "-x", "hip"] + COMMON + extra + ["-c", s, "-o", o]
+            if keep_asm:
+                cmd += ["-save-temps=obj"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=OBJ)
+    if force or _newer(OUT, objs):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, keep_asm="--asm" in sys.argv, verbose=True))

@@ -1,0 +1,38 @@
+// Shared host-side helpers of libdance_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dance_hip.h"
+
+namespace dance {
+
+// thread-local text returned by dance_last_error() (defined in exact_ops.hip)
+char *error_buffer();
+
+inline int fail(int code, const char *fn, const char *what)
+{
+    snprintf(error_buffer(), 512, "%s: %s", fn, what);
+    return code;
+}
+
+// after a launch: report launch-configuration errors without synchronising
+inline int launch_check(const char *fn)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        return 0;
+    return fail((int)e, fn, hipGetErrorString(e));
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace dance
+
+#define DANCE_REQUIRE(cond)                                                               \
+    do {                                                                                  \
+        if (!(cond))                                                                      \
+            return dance::fail((int)hipErrorInvalidValue, __func__,                       \
+                               "requirement failed: " #cond);                             \
+    } while (0)

@@ -1,0 +1,472 @@
+// exact_ops.hip -- the integer / index side of the contour path for gfx950:
+// the four `extreme_utils` ops and the fused polygon resampler.
+//
+// Built with -ffp-contract=off and correctly rounded fp32 divide/sqrt: every float
+// operation here is a separately rounded IEEE op, so counts, indices and resampled
+// coordinates are bit-identical to the reference's torch/CUDA op sequence
+// (oracle: oracle/extreme_utils_ref.c).
+#include <math.h>
+
+#include "common.h"
+
+namespace dance {
+static thread_local char g_error[512] = "";
+char *error_buffer() { return g_error; }
+}  // namespace dance
+
+using dance::ceil_div;
+using dance::launch_check;
+
+extern "C" int dance_abi_version(void) { return 1; }
+extern "C" const char *dance_last_error(void) { return dance::error_buffer(); }
+
+extern "C" int dance_device_info(int *cu_count_host, int *lds_bytes_host)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess)
+        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    if (cu_count_host)
+        *cu_count_host = p.multiProcessorCount;
+    if (lds_bytes_host)
+        *lds_bytes_host = (int)p.sharedMemPerBlock;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// collect_extreme_point: one wavefront per (batch, box, side).  The reference walks the
+// band around a box side with one thread (utils.cu:28-111); here the 64 lanes sweep the
+// band in memory order, each keeping its first best pixel, and a butterfly reduction
+// picks the highest score, ties going to the earliest position in the REFERENCE's scan
+// order -- which is what the serial strict '<' update (utils.cu:59,101) produces.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float cosine_to_centre(float cx, float cy, long long x, long long y,
+                                                  float u, float v)
+{
+    float dx = cx - (float)x;
+    float dy = cy - (float)y;
+    float n1 = sqrtf(u * u + v * v);
+    float n2 = sqrtf(dx * dx + dy * dy);
+    float dot = u * dx + v * dy;
+    return dot / (n1 * n2);
+}
+
+__global__ __launch_bounds__(256) void k_collect_extreme_point(
+    const float *__restrict__ ext_hm, const long long *__restrict__ bbox,
+    const long long *__restrict__ radius, const float *__restrict__ vote,
+    const float *__restrict__ ct, long long *__restrict__ out, int n, int h, int w)
+{
+    const int lane = threadIdx.x & 63;
+    const int dir = threadIdx.x >> 6;           // 0 top, 1 left, 2 bottom, 3 right
+    const long long bn = blockIdx.x;            // = ib * n + in
+    const long long ib = bn / n;
+    const float *hm = ext_hm + (ib * 4 + dir) * (long long)h * w;
+    const float *vt = vote + ib * (long long)h * w * 2;
+    const long long *bx = bbox + bn * 4;
+    // the reference narrows the int64 box to int (utils.cu:136-139), then widens again
+    const long long x_min = (int)bx[0], y_min = (int)bx[1];
+    const long long x_max = (int)bx[2], y_max = (int)bx[3];
+    const long long r = radius[bn];
+    const float cx = ct[bn * 2], cy = ct[bn * 2 + 1];
+    const bool horizontal = (dir & 1) == 0;
+
+    long long init_x, init_y, along_lo, along_n, side;
+    if (horizontal) {
+        side = dir == 0 ? y_min : y_max;
+        init_x = (x_min + x_max) / 2;
+        init_y = side;
+        along_lo = x_min;
+        along_n = x_max - x_min + 1;
+    } else {
+        side = dir == 1 ? x_min : x_max;
+        init_x = side;
+        init_y = (y_min + y_max) / 2;
+        along_lo = y_min;
+        along_n = y_max - y_min + 1;
+    }
+    const long long band = 2 * r + 1;
+    const long long total = (along_n > 0 && band > 0) ? along_n * band : 0;
+
+    float best = -INFINITY;
+    long long best_pos = -1;
+    for (long long q = lane; q < total; q += 64) {
+        long long x, y, pos;
+        if (horizontal) {                        // memory order == scan order
+            long long i = q / along_n, j = q - i * along_n;
+            y = side - r + i;
+            x = along_lo + j;
+            pos = q;
+        } else {                                 // memory order: x fastest
+            long long j = q / band, i = q - j * band;
+            x = side - r + i;
+            y = along_lo + j;
+            pos = i * along_n + j;               // reference order: column outer, row inner
+        }
+        if (x < 0 || x > w - 1 || y < 0 || y > h - 1)
+            continue;
+        const long long p = y * w + x;
+        const float s = hm[p];
+        const float c = cosine_to_centre(cx, cy, x, y, vt[p * 2], vt[p * 2 + 1]);
+        // utils.cu:54 compares against the double literal 0.9, :96 against int 0
+        const bool skip = horizontal ? ((double)c < 0.9) : (c < 0.0f);
+        if (skip)
+            continue;
+        if (s > best || (s == best && (best_pos < 0 || pos < best_pos))) {
+            best = s;
+            best_pos = pos;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float o_s = __shfl_xor(best, m, 64);
+        const long long o_p = __shfl_xor(best_pos, m, 64);
+        const bool take = o_p >= 0 && (best_pos < 0 || o_s > best || (o_s == best && o_p < best_pos));
+        if (take) {
+            best = o_s;
+            best_pos = o_p;
+        }
+    }
+    if (lane == 0) {
+        const bool init_in = init_x >= 0 && init_x <= w - 1 && init_y >= 0 && init_y <= h - 1;
+        const float init_score = init_in ? hm[init_y * w + init_x] : -INFINITY;
+        long long rx = init_x, ry = init_y;
+        if (best_pos >= 0 && init_score < best) {
+            if (horizontal) {
+                ry = side - r + best_pos / along_n;
+                rx = along_lo + best_pos % along_n;
+            } else {
+                rx = side - r + best_pos / along_n;
+                ry = along_lo + best_pos % along_n;
+            }
+        }
+        long long *o = out + (bn * 4 + dir) * 2;
+        o[0] = rx;
+        o[1] = ry;
+    }
+}
+
+extern "C" int dance_collect_extreme_point(const float *ext_hm, const int64_t *bbox,
+                                           const int64_t *radius, const float *vote,
+                                           const float *ct, int64_t *extreme_point, int b, int n,
+                                           int h, int w, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && n >= 0 && h > 0 && w > 0);
+    if (b == 0 || n == 0)
+        return 0;
+    DANCE_REQUIRE(ext_hm && bbox && radius && vote && ct && extreme_point);
+    DANCE_REQUIRE((long long)b * n < (1ll << 31));
+    hipLaunchKernelGGL(k_collect_extreme_point, dim3(b * n), dim3(256), 0, (hipStream_t)stream,
+                       ext_hm, (const long long *)bbox, (const long long *)radius, vote, ct,
+                       (long long *)extreme_point, n, h, w);
+    return launch_check(__func__);
+}
+
+// ------------------------------------------------------------------------------------
+// calculate_edge_num: serial by nature (walks the sorted edges until the surplus is
+// gone); one lane per polygon exactly as utils.cu:215-255, but the walk stops at the
+// last edge instead of running off the array when the surplus cannot be absorbed.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void fix_edge_counts(long long *cnt, const long long *order, int E,
+                                                long long sum, long long p_num)
+{
+    if (sum == p_num)
+        return;
+    if (sum < p_num) {
+        cnt[order[0]] += p_num - sum;
+        return;
+    }
+    long long surplus = sum - p_num;
+    for (int k = 0; k < E && surplus > 0; ++k) {
+        const long long e = order[k];
+        if (cnt[e] > surplus) {
+            cnt[e] -= surplus;
+            surplus = 0;
+        } else {
+            surplus -= cnt[e] - 1;
+            cnt[e] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_calculate_edge_num(long long *edge_num,
+                                                            const long long *edge_num_sum,
+                                                            const long long *edge_idx_sort,
+                                                            long long polys, int E, long long p_num)
+{
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= polys)
+        return;
+    fix_edge_counts(edge_num + i * E, edge_idx_sort + i * E, E, edge_num_sum[i], p_num);
+}
+
+extern "C" int dance_calculate_edge_num(int64_t *edge_num, const int64_t *edge_num_sum,
+                                        const int64_t *edge_idx_sort, int b, int n,
+                                        int orig_p_num, int64_t p_num, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && n >= 0 && orig_p_num > 0);
+    const long long polys = (long long)b * n;
+    if (polys == 0)
+        return 0;
+    DANCE_REQUIRE(edge_num && edge_num_sum && edge_idx_sort);
+    hipLaunchKernelGGL(k_calculate_edge_num, dim3((unsigned)((polys + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (long long *)edge_num, (const long long *)edge_num_sum,
+                       (const long long *)edge_idx_sort, polys, orig_p_num, (long long)p_num);
+    return launch_check(__func__);
+}
+
+// ------------------------------------------------------------------------------------
+// calculate_wnp: the reference gives one thread a whole edge and lets it loop over that
+// edge's points (utils.cu:303-331); here each output slot is one lane that looks up its
+// edge, so stores are coalesced and every slot is written exactly once.  Where edges
+// overlap (inconsistent input) the highest edge index wins, as in a serial e=0..E-1 walk.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_calculate_wnp(const long long *edge_num,
+                                                       const long long *edge_start_idx,
+                                                       float *weight, long long *ind,
+                                                       long long polys, int E, int p_num)
+{
+    const long long t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= polys * p_num)
+        return;
+    const long long poly = t / p_num;
+    const int slot = (int)(t - poly * p_num);
+    const long long *num = edge_num + poly * E;
+    const long long *start = edge_start_idx + poly * E;
+    float wv = 0.0f;
+    long long i0 = 0, i1 = 0;
+    for (int e = 0; e < E; ++e) {
+        const int s = (int)start[e];
+        const long long k = num[e];
+        if (slot >= s && (long long)slot - s < k) {
+            wv = (float)(slot - s) / (float)k;
+            i0 = e;
+            i1 = (e + 1) % E;
+        }
+    }
+    weight[t] = wv;
+    ind[t * 2] = i0;
+    ind[t * 2 + 1] = i1;
+}
+
+extern "C" int dance_calculate_wnp(const int64_t *edge_num, const int64_t *edge_start_idx,
+                                   float *weight, int64_t *ind, int b, int n, int orig_p_num,
+                                   int p_num, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && n >= 0 && orig_p_num > 0 && p_num >= 0);
+    const long long total = (long long)b * n * p_num;
+    if (total == 0)
+        return 0;
+    DANCE_REQUIRE(edge_num && edge_start_idx && weight && ind);
+    DANCE_REQUIRE(total < (1ll << 38));
+    hipLaunchKernelGGL(k_calculate_wnp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const long long *)edge_num,
+                       (const long long *)edge_start_idx, weight, (long long *)ind,
+                       (long long)b * n, orig_p_num, p_num);
+    return launch_check(__func__);
+}
+
+// ------------------------------------------------------------------------------------
+// roll_array: new[b][(i + step[b]) mod n][:] = old[b][i][:]  (utils.cu:377-401)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_roll_array(const float *__restrict__ array,
+                                                    const long long *__restrict__ step,
+                                                    float *__restrict__ out, long long total,
+                                                    int n, int d)
+{
+    const long long t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= total)
+        return;
+    const long long row = t / d;
+    const int col = (int)(t - row * d);
+    const long long ib = row / n;
+    const int i = (int)(row - ib * n);
+    const int s = (int)step[ib];                 // utils.cu:396 narrows to int
+    const int dst = ((i + s) % n + n) % n;
+    out[(ib * n + dst) * d + col] = array[t];
+}
+
+extern "C" int dance_roll_array(const float *array, const int64_t *step, float *new_array, int b,
+                                int n, int d, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && n >= 0 && d >= 0);
+    const long long total = (long long)b * n * d;
+    if (total == 0)
+        return 0;
+    DANCE_REQUIRE(array && step && new_array);
+    DANCE_REQUIRE(total < (1ll << 38));
+    hipLaunchKernelGGL(k_roll_array, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, array, (const long long *)step, new_array, total, n, d);
+    return launch_check(__func__);
+}
+
+// ------------------------------------------------------------------------------------
+// Fused resampler (snake_head.py:764-794 + utils.cu:215-331 + the polygon builders):
+// one wavefront per polygon.  Lanes build the polygon and its edge lengths in LDS; lane 0
+// runs the short serial part (left-to-right length sum, round-half-even counts, stable
+// descending sort, fix-up, prefix sum); then all lanes emit points, one slot per lane per
+// step, each finding its edge by a scan of the (<= 64) start indices.
+// ------------------------------------------------------------------------------------
+#define RS_MAX_E 64
+
+__global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *__restrict__ src,
+                                                         int E, int p_num, float *__restrict__ out,
+                                                         long long *__restrict__ start_out,
+                                                         int *__restrict__ status)
+{
+    __shared__ float px[RS_MAX_E], py[RS_MAX_E], len[RS_MAX_E];
+    __shared__ long long cnt[RS_MAX_E], start[RS_MAX_E];
+    __shared__ int order[RS_MAX_E];
+    __shared__ int ok;
+    const int lane = threadIdx.x;
+    const long long poly = blockIdx.x;
+
+    if (kind == DANCE_POLY_RAW) {
+        if (lane < E) {
+            px[lane] = src[(poly * E + lane) * 2];
+            py[lane] = src[(poly * E + lane) * 2 + 1];
+        }
+    } else if (kind == DANCE_POLY_BOX) {
+        // corners (xmax,ymin) (xmin,ymin) (xmin,ymax) (xmax,ymax): snake_head.py:878
+        if (lane < 4) {
+            const float *b = src + poly * 4;
+            px[lane] = (lane == 0 || lane == 3) ? b[2] : b[0];
+            py[lane] = (lane < 2) ? b[1] : b[3];
+        }
+    } else if (kind == DANCE_POLY_QUAD) {
+        // edge mid-points top, left, bottom, right: dsnake_head.py:506-515
+        if (lane < 4) {
+            const float *b = src + poly * 4;
+            const float mx = (b[0] + b[2]) / 2.0f, my = (b[1] + b[3]) / 2.0f;
+            px[lane] = lane == 1 ? b[0] : (lane == 3 ? b[2] : mx);
+            py[lane] = lane == 0 ? b[1] : (lane == 2 ? b[3] : my);
+        }
+    } else {
+        // 12-gon from extreme points t,l,b,r: snake_head.py:800-830
+        if (lane < 12) {
+            const float *e = src + poly * 8;
+            const float tx = e[0], ty = e[1], lx = e[2], ly = e[3];
+            const float bx = e[4], by = e[5], rx = e[6], ry = e[7];
+            const float w8 = (rx - lx) / 8.0f, h8 = (by - ty) / 8.0f;
+            float x, y;
+            switch (lane) {
+            case 0: x = tx; y = ty; break;
+            case 1: x = fmaxf(tx - w8, lx); y = ty; break;
+            case 2: x = lx; y = fmaxf(ly - h8, ty); break;
+            case 3: x = lx; y = ly; break;
+            case 4: x = lx; y = fminf(ly + h8, by); break;
+            case 5: x = fmaxf(bx - w8, lx); y = by; break;
+            case 6: x = bx; y = by; break;
+            case 7: x = fminf(bx + w8, rx); y = by; break;
+            case 8: x = rx; y = fminf(ry + h8, by); break;
+            case 9: x = rx; y = ry; break;
+            case 10: x = rx; y = fmaxf(ry - h8, ty); break;
+            default: x = fminf(tx + w8, rx); y = ty; break;
+            }
+            px[lane] = x;
+            py[lane] = y;
+        }
+    }
+    __syncthreads();
+    if (lane < E) {
+        const int nx = lane + 1 == E ? 0 : lane + 1;
+        const float dx = px[nx] - px[lane], dy = py[nx] - py[lane];
+        const float sx = dx * dx, sy = dy * dy;
+        len[lane] = sqrtf(sx + sy);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float total = 0.0f;
+        for (int e = 0; e < E; ++e)
+            total = total + len[e];
+        long long sum = 0;
+        for (int e = 0; e < E; ++e) {
+            const float q = (len[e] * (float)p_num) / total;
+            const float r = rintf(q);                       // torch.round: half to even
+            // NaN/inf -> INT64_MIN is what torch's .long() yields on the reference's CPU path
+            long long c = (r == r && fabsf(r) < 9.0e18f) ? (long long)r : (long long)(-9223372036854775807ll - 1);
+            if (c < 1)
+                c = 1;
+            cnt[e] = c;
+            sum += c;
+            order[e] = e;
+        }
+        // stable descending insertion sort == torch.argsort(descending=True), ties low index first
+        for (int a = 1; a < E; ++a) {
+            const int key = order[a];
+            int j = a - 1;
+            while (j >= 0 && cnt[order[j]] < cnt[key]) {
+                order[j + 1] = order[j];
+                --j;
+            }
+            order[j + 1] = key;
+        }
+        if (sum != (long long)p_num) {
+            if (sum < (long long)p_num) {
+                cnt[order[0]] += p_num - sum;
+            } else {
+                long long surplus = sum - p_num;
+                for (int k = 0; k < E && surplus > 0; ++k) {
+                    const int e = order[k];
+                    if (cnt[e] > surplus) {
+                        cnt[e] -= surplus;
+                        surplus = 0;
+                    } else {
+                        surplus -= cnt[e] - 1;
+                        cnt[e] = 1;
+                    }
+                }
+            }
+        }
+        long long acc = 0;
+        for (int e = 0; e < E; ++e) {
+            start[e] = acc;
+            acc += cnt[e];
+        }
+        ok = acc == (long long)p_num;
+        status[poly] = ok ? 0 : 1;
+    }
+    __syncthreads();
+    if (start_out != nullptr && lane < E)
+        start_out[poly * E + lane] = start[lane];
+    float *o = out + poly * p_num * 2;
+    if (!ok) {
+        for (int s = lane; s < p_num * 2; s += 64)
+            o[s] = 0.0f;
+        return;
+    }
+    for (int s = lane; s < p_num; s += 64) {
+        int e = 0;
+        for (int k = 1; k < E; ++k)
+            e = (start[k] <= s) ? k : e;
+        const int nx = e + 1 == E ? 0 : e + 1;
+        const float wgt = (float)(s - (int)start[e]) / (float)cnt[e];
+        const float om = 1.0f - wgt;
+        const float x = px[e] * om, x2 = px[nx] * wgt;
+        const float y = py[e] * om, y2 = py[nx] * wgt;
+        o[s * 2] = x + x2;
+        o[s * 2 + 1] = y + y2;
+    }
+}
+
+extern "C" int dance_uniform_upsample(int kind, const float *src, int n, int e, int p_num,
+                                      float *out, int64_t *edge_start_idx, int32_t *status,
+                                      void *stream)
+{
+    DANCE_REQUIRE(kind >= DANCE_POLY_RAW && kind <= DANCE_POLY_OCTAGON);
+    DANCE_REQUIRE(n >= 0 && p_num >= 1 && p_num <= 4096);
+    if (kind == DANCE_POLY_BOX || kind == DANCE_POLY_QUAD)
+        DANCE_REQUIRE(e == 4);
+    if (kind == DANCE_POLY_OCTAGON)
+        DANCE_REQUIRE(e == 12);
+    DANCE_REQUIRE(e >= 1 && e <= RS_MAX_E);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(src && out && status);
+    hipLaunchKernelGGL(k_uniform_upsample, dim3(n), dim3(64), 0, (hipStream_t)stream, kind, src, e,
+                       p_num, out, (long long *)edge_start_idx, (int *)status);
+    return launch_check(__func__);
+}

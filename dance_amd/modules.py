@@ -1,0 +1,364 @@
+"""Drop-in snake-head modules with the reference's constructor / forward signature and
+state-dict keys, running the contour path on the gfx950 kernels.
+
+    RefineNet(cfg)   <- core/modeling/edge_snake/snake_head.py:433  (DANCE)
+    DsnakeHead(cfg)  <- core/modeling/dsnake_baseline/dsnake_head.py:197  (deep-snake variant)
+
+    forward(features, pred_instances=None, targets=None) -> (list[Instances], {})
+
+`features` is what the reference's callers pass (edge_det.py:387 / dsnake_head.py:193): the
+stride-4 map (B, [1+]C, Hf, Wf), channel 0 being the attention map when ATTENTION is on.
+`pred_instances` only need `.pred_boxes.tensor`, `.image_size`, `.has(name)`,
+`.ext_points.tensor` and attribute assignment (detectron2 `Instances` do; no detectron2
+import happens here).  Parameters live in ordinary nn.Modules so that
+`load_state_dict` of a reference checkpoint works key for key; `bottom_out` (2 x conv3x3
++ GroupNorm + ReLU, snake_head.py:562-615) stays torch.nn and is run channels_last so its
+output already is the NHWC layout the gather wants.
+
+Inference only: the training branch (target matching with Shapely/NumPy on the CPU,
+snake_head.py:982-1384) is outside the built path and raises.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .config import SnakeHeadConfig
+from .snake import ContourDeformer, SnakeNetWeights, sub_state_dict
+from .structures import ExtremePoints, PolygonPoints
+
+
+# ----------------------------------------------------------------- parameter containers
+class DilatedCircularConv(nn.Module):
+    """Parameter holder for snake_head.py:92-116 (`fc` = Conv1d k=9)."""
+
+    def __init__(self, state_dim, out_state_dim=None, n_adj=4, dilation=1):
+        super().__init__()
+        self.n_adj, self.dilation = n_adj, dilation
+        out_state_dim = state_dim if out_state_dim is None else out_state_dim
+        self.fc = nn.Conv1d(state_dim, out_state_dim, kernel_size=n_adj * 2 + 1, dilation=dilation)
+
+
+class SnakeBlock(nn.Module):
+    """Parameter holder for snake_head.py:140-153 (conv -> ReLU -> BatchNorm1d)."""
+
+    def __init__(self, state_dim, out_state_dim, n_adj=4, dilation=1):
+        super().__init__()
+        self.conv = DilatedCircularConv(state_dim, out_state_dim, n_adj, dilation)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm = nn.BatchNorm1d(out_state_dim)
+
+
+class _SnakeNet(nn.Module):
+    """Parameter holder for snake_head.py:220-258 / dsnake_head.py:95-117."""
+
+    def __init__(self, state_dim, feature_dim, dilations):
+        super().__init__()
+        self.head = SnakeBlock(feature_dim, state_dim)
+        self.res_layer_num = len(dilations)
+        self.dilations = tuple(dilations)
+        for i, d in enumerate(dilations):
+            setattr(self, "res" + str(i), SnakeBlock(state_dim, state_dim, n_adj=4, dilation=d))
+        fusion_state_dim = 256
+        self.fusion = nn.Conv1d(state_dim * (self.res_layer_num + 1), fusion_state_dim, 1)
+        self.prediction = nn.Sequential(
+            nn.Conv1d(state_dim * (self.res_layer_num + 1) + fusion_state_dim, 256, 1),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(256, 64, 1),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(64, 2, 1),
+        )
+
+
+class _ConvNormAct(nn.Conv2d):
+    """conv3x3 (+ GroupNorm) + ReLU with detectron2.layers.Conv2d's state-dict keys
+    (`weight`, `norm.weight`, `norm.bias`)."""
+
+    def __init__(self, cin, cout, dilation, norm):
+        super().__init__(cin, cout, kernel_size=3, stride=1, padding=1, dilation=dilation,
+                         bias=not norm)
+        self.norm = nn.GroupNorm(32, cout) if norm == "GN" else None
+
+    def forward(self, x):
+        x = super().forward(x)
+        if self.norm is not None:
+            x = self.norm(x)
+        return F.relu(x)
+
+
+def _reference_init(module):
+    # snake_head.py:632-641 / dsnake_head.py:255-259
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+            m.weight.data.normal_(0.0, 0.01)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+class _SnakeHeadBase(nn.Module):
+    def _pack(self, names):
+        """(Re)pack the deformers for the kernels when parameters changed or moved."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("dance_amd modules run on a GPU only (module is on %s); "
+                               "there is no CPU fallback" % dev)
+        sig = (dev,) + tuple(int(p._version) for p in self.parameters()) + \
+              tuple(int(b._version) for b in self.buffers())
+        if getattr(self, "_packed_sig", None) != sig:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._packed = {n: SnakeNetWeights(sub_state_dict(sd, n + "."), dev,
+                                               getattr(self, n).dilations) for n in names}
+            self._packed_sig = sig
+        return self._packed
+
+    def _bottom(self, feats):
+        """bottom_out in channels_last; returns NHWC (B,Hf,Wf,C) contiguous memory."""
+        if len(self.bottom_out) == 0:
+            return None
+        x = feats.contiguous(memory_format=torch.channels_last)
+        for conv in self.bottom_out:
+            x = conv(x)
+        x = x.permute(0, 2, 3, 1)
+        return x if x.is_contiguous() else x.contiguous()
+
+
+# ------------------------------------------------------------------------------ DANCE
+class RefineNet(_SnakeHeadBase):
+    def __init__(self, cfg, polygon_cls=PolygonPoints):
+        super().__init__()
+        c = SnakeHeadConfig.from_cfg(cfg)
+        c.validate()
+        self.cfg = c
+        self.polygon_cls = polygon_cls
+        self.initial = c.initial
+        self.num_iter = c.num_iter
+        self.num_convs = c.num_convs
+        self.num_sampling = c.num_sampling
+        self.de_location_type = c.de_loc_type
+        self.individual_scale = c.individual_scale
+        self.attention = c.attention
+        self.visualize_path = c.vis_path
+        self.bottom_out = nn.ModuleList(
+            [_ConvNormAct(c.convs_dim, c.convs_dim, c.dilations[i], c.norm) for i in range(c.num_convs)])
+        for i in range(len(c.num_iter)):
+            setattr(self, "deformer" + str(i), _SnakeNet(c.feat_dim, c.convs_dim + 2, c.cir_dilations[i]))
+        _reference_init(self)
+        self._deformer = None
+
+    # -- initial contours ----------------------------------------------------------
+    def uniform_upsample(self, poly, p_num):
+        """snake_head.py:764-794 on (1,N,E,2) -> ((N,p,2), edge_start_idx (N,E))."""
+        if poly.size(1) == 0:
+            return torch.zeros([0, p_num, 2], device=poly.device), None
+        return ops.uniform_upsample(poly, p_num)
+
+    def get_octagon(self, ex, p_num):
+        """snake_head.py:796-832."""
+        if len(ex) == 0:
+            return torch.zeros([0, p_num, 2], device=ex.device), None
+        return ops.uniform_upsample(ex, p_num, kind=ops.POLY_OCTAGON)
+
+    def _sample_boxes(self, pred_instances):
+        """sample_bboxes_fast / single_sample_bboxes_fast (snake_head.py:865-886, 911-924):
+        every image's boxes resampled in one launch."""
+        boxes = [x.pred_boxes.tensor for x in pred_instances]
+        allb = torch.cat(boxes, dim=0) if len(boxes) > 1 else boxes[0]
+        locs, _ = ops.uniform_upsample(allb, self.num_sampling, kind=ops.POLY_BOX) if len(allb) else \
+            (torch.zeros([0, self.num_sampling, 2], device=allb.device), None)
+        idx = torch.cat([b.new_empty(len(b)).fill_(i) for i, b in enumerate(boxes)])
+        return locs, idx
+
+    def _sample_octagons(self, pred_instances):
+        """sample_octagons_fast (snake_head.py:844-863), incl. the in-place fit_to_box /
+        clamp of the instances' extreme points."""
+        locs, idx = [], []
+        for i, inst in enumerate(pred_instances):
+            if inst.has("ext_points"):
+                h, w = inst.image_size
+                inst.ext_points.fit_to_box()
+                ext = inst.ext_points.tensor
+                ext[..., 0].clamp_(min=0, max=w - 1)
+                ext[..., 1].clamp_(min=0, max=h - 1)
+                locs.append(self.get_octagon(ext, self.num_sampling)[0])
+                idx.append(ext.new_empty(len(ext)).fill_(i))
+        if not locs:
+            return locs, idx
+        return torch.cat(locs, dim=0), torch.cat(idx)
+
+    # -- the path ------------------------------------------------------------------
+    def _get_deformer(self):
+        names = ["deformer%d" % i for i in range(len(self.num_iter))]
+        packed = self._pack(names)
+        if self._deformer is None or self._deformer.nets[0] is not packed[names[0]]:
+            self._deformer = ContourDeformer([packed[n] for n in names], padding="reflection",
+                                             de_loc_type=self.de_location_type,
+                                             individual_scale=self.individual_scale,
+                                             attention=self.attention)
+        return self._deformer
+
+    def _features(self, features):
+        """Attention split (snake_head.py:1812-1814) + bottom_out (1816-1820) ->
+        (feat NHWC, att plane); the re-concatenation of :1824 is never materialised."""
+        d = self._get_deformer()
+        if self.attention:
+            att, feats = features[:, 0].contiguous(), features[:, 1:]
+        else:
+            att, feats = None, features
+        nhwc = self._bottom(feats)
+        if nhwc is None:
+            nhwc, _ = ops.nchw_to_nhwc(feats.contiguous(), 0)
+        return d, nhwc.float(), att
+
+    def deform(self, features, locations, image_idx, image_sizes, whs):
+        """The `snake_deformation` scope (snake_head.py:1822-1862): per-iteration contours."""
+        d, nhwc, att = self._features(features)
+        return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc")
+
+    def single_test(self, features, pred_instances):
+        """snake_head.py:1763-1869 (one image)."""
+        if self.initial == "octagon":
+            locations, _ = self._sample_octagons(pred_instances)
+        elif self.initial == "box":
+            locations, _ = self._sample_boxes(pred_instances[:1])
+        else:
+            raise ValueError("Invalid initial!")
+        if len(locations) == 0:
+            return pred_instances, {}
+        image_sizes = pred_instances[0].image_size
+        pred_instances[0].pred_boxes.clip(image_sizes)
+        bboxes = pred_instances[0].pred_boxes.tensor
+        whs = torch.stack([bboxes[:, 2] - bboxes[:, 0], bboxes[:, 3] - bboxes[:, 1]], dim=1)
+        preds = self.deform(features, locations, None, image_sizes, whs)
+        inst = pred_instances[0]
+        inst.pred_polys = self.polygon_cls(preds[-1])
+        return [inst], {}
+
+    def forward(self, features, pred_instances=None, targets=None):
+        """snake_head.py:1871-2385, inference branches."""
+        if self.training:
+            raise NotImplementedError("dance_amd.RefineNet is inference-only (call .eval())")
+        if not self.visualize_path:
+            return self.single_test(features, pred_instances)
+        assert pred_instances is not None
+        if self.initial == "octagon":
+            locations, image_idx = self._sample_octagons(pred_instances)
+        elif self.initial == "box":
+            locations, image_idx = self._sample_boxes(pred_instances)
+        else:
+            raise ValueError("Invalid initial!")
+        if len(locations) == 0:
+            return pred_instances, {}
+        image_sizes = [x.image_size for x in pred_instances]
+        bboxes = torch.cat([x.pred_boxes.tensor for x in pred_instances], dim=0)
+        whs = torch.stack([bboxes[:, 2] - bboxes[:, 0], bboxes[:, 3] - bboxes[:, 1]], dim=1)
+        preds = self.deform(features, locations, image_idx, image_sizes, whs)
+        # predict_postprocess, snake_head.py:2399-2445
+        results = []
+        for i, inst in enumerate(pred_instances):
+            sel = image_idx == i
+            inst.pred_polys = self.polygon_cls(preds[-1][sel])
+            path = [locations[sel]] + [p[sel] for p in preds if p.size(1) == self.num_sampling]
+            inst.pred_path = torch.stack(path, dim=1)
+            results.append(inst)
+        return results, {}
+
+
+# ------------------------------------------------------------------------------ Dsnake
+class DsnakeHead(_SnakeHeadBase):
+    def __init__(self, cfg, polygon_cls=PolygonPoints, extreme_cls=ExtremePoints):
+        super().__init__()
+        c = SnakeHeadConfig.from_cfg(cfg)
+        c.validate()
+        self.cfg = c
+        self.polygon_cls, self.extreme_cls = polygon_cls, extreme_cls
+        self.num_iter = c.num_iter
+        self.num_convs = c.num_convs
+        self.num_sampling = c.num_sampling
+        self.visualize_path = c.vis_path
+        dil = (1, 1, 1, 2, 2, 4, 4)                                   # dsnake_head.py:102
+        self.bottom_out = nn.ModuleList(
+            [_ConvNormAct(c.convs_dim, c.convs_dim, c.dilations[i], c.norm) for i in range(c.num_convs)])
+        self.fuse = nn.Conv1d(2 * c.convs_dim, c.convs_dim, 1)
+        self.init_snake = _SnakeNet(128, c.convs_dim + 2, dil)
+        for i in range(len(c.num_iter)):
+            setattr(self, "deformer" + str(i), _SnakeNet(128, c.convs_dim + 2, dil))
+        _reference_init(self)
+        self._deformer = None
+        self._fuse_sig = None
+
+    def _get_deformer(self):
+        names = ["init_snake"] + ["deformer%d" % i for i in range(len(self.num_iter))]
+        packed = self._pack(names)
+        if self._deformer is None or self._deformer.nets[0] is not packed[names[0]]:
+            self._deformer = ContourDeformer([packed[n] for n in names], padding="zeros",
+                                             de_loc_type="demin", individual_scale=False,
+                                             attention=False)
+            w = self.fuse.weight.detach().float()                     # (C, 2C, 1)
+            c = w.shape[0]
+            self._fuse_w_sampled = ops.pack_conv_weight(w[:, :c, :])
+            self._fuse_wg_center = w[:, c:, 0].t().contiguous()       # [g][o]
+            self._fuse_b = self.fuse.bias.detach().float().contiguous()
+        return self._deformer
+
+    def init_stage(self, d, feat, init_locations, idx):
+        """DsnakeHead.init (dsnake_head.py:718-746): 40-point quadrangle + centre feature
+        -> fuse Conv1d -> init snake -> 4 extreme points."""
+        c = feat.shape[-1]
+        sampled, _ = ops.gather_features(feat, None, init_locations, idx, ops.PAD_ZEROS, "demin")
+        center = (torch.min(init_locations, dim=1)[0] + torch.max(init_locations, dim=1)[0]) * 0.5
+        cfeat, _ = ops.gather_features(feat, None, center[:, None].contiguous(), idx, ops.PAD_ZEROS, None)
+        # centre half of `fuse` is vertex-invariant: fold it into a per-contour row constant
+        rowinit = ops.row_constant(cfeat[:, :, 0], self._fuse_wg_center, self._fuse_b)
+        n, _, v = sampled.shape
+        x = torch.empty((n, c + 2, v), dtype=torch.float32, device=feat.device)
+        ops.circconv(sampled, self._fuse_w_sampled, None, cin=c, rowinit=rowinit,
+                     out=x[:, :c])
+        x[:, c:] = sampled[:, c:]
+        pred = d.evolve(0, feat, None, init_locations, idx, None, use_att=False, clip_first=False,
+                        clip_max=(0.0, 0.0), x_in=x)
+        return pred[:, ::10]
+
+    def forward(self, features, pred_instances=None, targets=None):
+        """dsnake_head.py:767-855, inference branch."""
+        if self.training:
+            raise NotImplementedError("dance_amd.DsnakeHead is inference-only (call .eval())")
+        assert pred_instances is not None
+        boxes = [x.pred_boxes.tensor for x in pred_instances]
+        allb = torch.cat(boxes, dim=0)
+        if len(allb) == 0:
+            return pred_instances, {}
+        init_locations, _ = ops.uniform_upsample(allb, 40, kind=ops.POLY_QUAD)   # :438-451
+        image_idx = torch.cat([b.new_empty(len(b)).fill_(i) for i, b in enumerate(boxes)])
+        idx = image_idx.to(torch.int32)
+        d = self._get_deformer()
+        nhwc = self._bottom(features)
+        if nhwc is None:
+            nhwc, _ = ops.nchw_to_nhwc(features.contiguous(), 0)
+        nhwc = nhwc.float()
+        pred_exts = self.init_stage(d, nhwc, init_locations, idx)
+        h, w = nhwc.shape[1] * 4, nhwc.shape[2] * 4
+        exts = pred_exts.clone()
+        exts[..., 0] = torch.clamp(exts[..., 0], min=0, max=w - 1)               # :800-805
+        exts[..., 1] = torch.clamp(exts[..., 1], min=0, max=h - 1)
+        for i, inst in enumerate(pred_instances):
+            if not inst.has("ext_points"):
+                inst.ext_points = self.extreme_cls(exts[image_idx == i])
+            else:                                    # GT extreme points given (:811-817)
+                exts[image_idx == i] = inst.ext_points.tensor
+        locations, _ = ops.uniform_upsample(exts.contiguous(), self.num_sampling, kind=ops.POLY_OCTAGON)
+        preds, cur = [], locations
+        for i in range(len(self.num_iter)):
+            cur = d.evolve(1 + i, nhwc, None, cur, idx, None, use_att=False, clip_first=False,
+                           clip_max=(0.0, 0.0))
+            preds.append(cur)
+        results = []
+        for i, inst in enumerate(pred_instances):                                 # :857-877
+            sel = image_idx == i
+            inst.pred_polys = self.polygon_cls(preds[-1][sel])
+            if self.visualize_path:
+                path = [locations[sel]] + [p[sel] for p in preds[:-1]]
+                inst.pred_path = torch.stack(path, dim=1)
+            results.append(inst)
+        self.last_stages = {"init": init_locations, "exts_raw": pred_exts, "exts": exts,
+                            "octagons": locations, "preds": preds}
+        return results, {}

@@ -1,0 +1,156 @@
+"""Tensor-level wrappers over the C ABI (include/dance_hip.h): validation, output
+allocation and stream plumbing only -- all arithmetic happens in libdance_hip.so.
+
+Every function requires CUDA(HIP) tensors and raises RuntimeError otherwise; there is no
+CPU or torch fallback.
+"""
+import torch
+
+from ._lib import check, current_stream, lib, ptr
+
+POLY_RAW, POLY_BOX, POLY_QUAD, POLY_OCTAGON = 0, 1, 2, 3
+PAD_ZEROS, PAD_REFLECTION = 0, 1
+DELOC = {"derange": 0, "demean": 1, "demin": 2, None: 3, "none": 3}
+EP_RELU, EP_AFFINE, EP_RESIDUAL, EP_ROWINIT, EP_MAXV = 1, 2, 4, 8, 16
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dance_amd ops need GPU tensors (got a %s tensor)" % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected a float32 tensor, got %s" % t.dtype)
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- resampler
+def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True):
+    """Fused RefineNet.uniform_upsample (snake_head.py:764-794).
+
+    kind RAW:     poly (N,E,2) [or the reference's (1,N,E,2)] polygon vertices
+    kind BOX/QUAD: poly (N,4) xyxy boxes;  kind OCTAGON: poly (N,4,2) extreme points
+    Returns (points (N,p_num,2) f32, edge_start_idx (N,E) i64).  With `check_status` the
+    reference's `assert torch.all(edge_num_sum == p_num)` (snake_head.py:782) is kept,
+    which -- like the reference -- synchronises with the device.
+    """
+    _need_gpu(poly)
+    if kind == POLY_RAW and poly.dim() == 4:
+        if poly.size(0) != 1:
+            raise RuntimeError("uniform_upsample: leading batch dim must be 1")
+        poly = poly[0]
+    poly = _f32c(poly)
+    n = poly.size(0)
+    if kind == POLY_RAW:
+        e = poly.size(1)
+    elif kind in (POLY_BOX, POLY_QUAD):
+        if poly.dim() != 2 or poly.size(1) != 4:
+            raise RuntimeError("uniform_upsample: boxes must be (N,4)")
+        e = 4
+    else:
+        if poly.dim() != 3 or tuple(poly.shape[1:]) != (4, 2):
+            raise RuntimeError("uniform_upsample: extreme points must be (N,4,2)")
+        e = 12
+    out = torch.empty((n, p_num, 2), dtype=torch.float32, device=poly.device)
+    start = torch.empty((n, e), dtype=torch.int64, device=poly.device)
+    status = torch.empty((n,), dtype=torch.int32, device=poly.device)
+    with torch.cuda.device(poly.device):
+        check(lib().dance_uniform_upsample(kind, ptr(poly), n, e, int(p_num), ptr(out), ptr(start),
+                                           ptr(status), current_stream()), "uniform_upsample")
+    if check_status and n:
+        assert not bool(status.any()), "uniform_upsample: edge counts do not sum to p_num"
+    return out, start
+
+
+# ------------------------------------------------------------------------------ layout
+def nchw_to_nhwc(features, att_channels):
+    """(B, att+C, Hf, Wf) NCHW -> ((B,Hf,Wf,C) NHWC, (B,Hf,Wf) attention plane or None)."""
+    _need_gpu(features)
+    features = _f32c(features)
+    b, ct, hf, wf = features.shape
+    c = ct - att_channels
+    feat = torch.empty((b, hf, wf, c), dtype=torch.float32, device=features.device)
+    att = torch.empty((b, hf, wf), dtype=torch.float32, device=features.device) if att_channels else None
+    with torch.cuda.device(features.device):
+        check(lib().dance_nchw_to_nhwc(ptr(features), ptr(feat), ptr(att), b, ct, att_channels,
+                                       hf * wf, current_stream()), "nchw_to_nhwc")
+    return feat, att
+
+
+# ------------------------------------------------------------------------------ gather
+def gather_features(feat_nhwc, att, locations, image_idx, padding_mode, deloc):
+    """get_locations_feature + de_location + concat (snake_head.py:1542-1652).
+
+    Returns (x (N, C+2 or C, V) channel-major, att_scores (N,V) or None)."""
+    _need_gpu(feat_nhwc, att, locations, image_idx)
+    feat_nhwc, locations = _f32c(feat_nhwc), _f32c(locations)
+    b, hf, wf, c = feat_nhwc.shape
+    n, v, _ = locations.shape
+    deloc_t = DELOC[deloc]
+    if image_idx is not None:
+        image_idx = image_idx.to(torch.int32).contiguous()
+    x = torch.empty((n, c + (2 if deloc_t != 3 else 0), v), dtype=torch.float32, device=locations.device)
+    att_out = torch.empty((n, v), dtype=torch.float32, device=locations.device) if att is not None else None
+    with torch.cuda.device(locations.device):
+        check(lib().dance_gather_features(ptr(feat_nhwc), ptr(att), ptr(locations), ptr(image_idx),
+                                          ptr(x), ptr(att_out), n, v, b, hf, wf, c, padding_mode,
+                                          deloc_t, current_stream()), "gather_features")
+    return x, att_out
+
+
+# ------------------------------------------------------------------------ snake blocks
+def pack_conv_weight(weight):
+    """Conv1d weight (Cout, Cin, K) -> packed (K, Cin_pad16, Cout) f32 with zero pad rows."""
+    cout, cin, k = weight.shape
+    cin_pad = (cin + 15) // 16 * 16
+    w = torch.zeros((k, cin_pad, cout), dtype=torch.float32, device=weight.device)
+    w[:, :cin, :] = weight.float().permute(2, 1, 0)
+    return w.contiguous()
+
+
+def circconv(x, w_packed, bias, *, cin, dilation=1, scale=None, shift=None, residual=None,
+             rowinit=None, relu=False, maxv=False, out=None):
+    """One circular dilated Conv1d block on channel-major activations (N,Cin,V).
+
+    w_packed from `pack_conv_weight`; scale/shift = folded eval-BatchNorm; returns
+    (N,Cout,V), or (N,Cout) with `maxv` (max over the ring)."""
+    _need_gpu(x, w_packed)
+    if x.dtype != torch.float32 or x.stride(2) != 1 or x.stride(1) != x.size(2):
+        x = _f32c(x)
+    n, cx, v = x.shape
+    taps, cin_pad, cout = w_packed.shape
+    if cx < cin or cin_pad != (cin + 15) // 16 * 16:
+        raise RuntimeError("circconv: weight/input channel mismatch")
+    flags = (EP_RELU if relu else 0) | (EP_AFFINE if scale is not None else 0) | \
+            (EP_RESIDUAL if residual is not None else 0) | (EP_ROWINIT if rowinit is not None else 0) | \
+            (EP_MAXV if maxv else 0)
+    if out is None:
+        out = torch.empty((n, cout) if maxv else (n, cout, v), dtype=torch.float32, device=x.device)
+    elif not maxv and (out.stride(2) != 1 or out.stride(1) != v or out.dtype != torch.float32):
+        raise RuntimeError("circconv: `out` must be channel-major (N,Cout,V) with dense rows")
+    y_stride = 0 if maxv else out.stride(0)
+    if residual is not None:
+        residual = _f32c(residual)
+        if y_stride != cout * v:
+            raise RuntimeError("circconv: residual needs a dense output")
+    with torch.cuda.device(x.device):
+        check(lib().dance_circconv(ptr(x), x.stride(0), ptr(w_packed), ptr(bias), ptr(scale),
+                                   ptr(shift), ptr(residual), ptr(rowinit), ptr(out), y_stride,
+                                   n, v, cin, cout, taps, dilation, flags, current_stream()),
+              "circconv")
+    return out
+
+
+def row_constant(g, wg, bias):
+    """h[n][o] = bias[o] + sum_k wg[k][o] * g[n][k]  (vertex-invariant columns of a k=1 conv)."""
+    _need_gpu(g, wg, bias)
+    g, wg, bias = _f32c(g), _f32c(wg), _f32c(bias)
+    n, gd = g.shape
+    cout = wg.size(1)
+    h = torch.empty((n, cout), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        check(lib().dance_row_constant(ptr(g), ptr(wg), ptr(bias), ptr(h), n, gd, cout,
+                                       current_stream()), "row_constant")
+    return h

@@ -1,0 +1,197 @@
+"""Host side of the contour-deformation path: weight packing and the iteration driver.
+
+`ContourDeformer.deform` is the tensor-level API the benchmark and the tests use
+(features + initial contours in, one deformed contour tensor per iteration out); the
+drop-in modules in dance_amd/modules.py wrap it behind the reference's
+`forward(features, pred_instances, targets)` interface.
+
+Every arithmetic step runs in libdance_hip.so (see include/dance_hip.h); this file only
+re-lays-out parameters once and enqueues `dance_snake_evolve` per iteration.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import EVOLVE_EVENTS, SnakeNetStruct, check, current_stream, lib, ptr
+
+BN_EPS = 1e-5                          # nn.BatchNorm1d default, snake_head.py:146
+DEFAULT_DILATIONS = (1, 1, 1, 2, 2, 4, 4)   # defaults.py:60-64 / dsnake_head.py:102
+
+
+def _fold_bn(sd, prefix):
+    """Eval BatchNorm1d as y*scale + shift -- the same folded form torch's CPU kernel
+    evaluates (alpha = w * invstd, beta = b - mean * alpha)."""
+    w, b = sd[prefix + "weight"].float(), sd[prefix + "bias"].float()
+    mean, var = sd[prefix + "running_mean"].float(), sd[prefix + "running_var"].float()
+    invstd = 1.0 / torch.sqrt(var + BN_EPS)
+    scale = w * invstd
+    return scale.contiguous(), (b - mean * scale).contiguous()
+
+
+class SnakeNetWeights:
+    """One `_SnakeNet` (snake_head.py:220-284 / dsnake_head.py:95-136) packed for the
+    kernels: conv weights as (tap, cin_pad16, cout), BatchNorm folded to scale/shift,
+    prediction[0] split into its global-state columns (256, hoisted per contour) and its
+    per-vertex columns (1024)."""
+
+    def __init__(self, sd, device, dilations=DEFAULT_DILATIONS):
+        if len(dilations) != 7:
+            raise ValueError("the kernels implement the 8-layer snake (head + 7 residual blocks)")
+        dev = torch.device(device)
+        g = lambda k: sd[k].detach().to(dev, torch.float32)   # noqa: E731
+        sdd = {k: g(k) for k in sd if not k.endswith("num_batches_tracked")}
+        self.dilations = tuple(int(d) for d in dilations)
+        self.state_dim = sdd["head.conv.fc.weight"].shape[0]
+        self.feature_dim = sdd["head.conv.fc.weight"].shape[1]      # C + 2
+        if self.state_dim != 128 or sdd["fusion.weight"].shape[:2] != (256, 1024):
+            raise ValueError("unsupported snake geometry (need state_dim 128, 8 states, fusion 256)")
+        t = {}
+        t["head_w"] = ops.pack_conv_weight(sdd["head.conv.fc.weight"])
+        t["head_b"] = sdd["head.conv.fc.bias"].contiguous()
+        t["head_scale"], t["head_shift"] = _fold_bn(sdd, "head.norm.")
+        for i in range(7):
+            t["res%d_w" % i] = ops.pack_conv_weight(sdd["res%d.conv.fc.weight" % i])
+            t["res%d_b" % i] = sdd["res%d.conv.fc.bias" % i].contiguous()
+            t["res%d_scale" % i], t["res%d_shift" % i] = _fold_bn(sdd, "res%d.norm." % i)
+        t["fusion_w"] = ops.pack_conv_weight(sdd["fusion.weight"])
+        t["fusion_b"] = sdd["fusion.bias"].contiguous()
+        p0 = sdd["prediction.0.weight"]                              # (256, 1280, 1)
+        t["pred0_wg"] = p0[:, :256, 0].t().contiguous()              # [g][o]
+        t["pred0_ws"] = ops.pack_conv_weight(p0[:, 256:, :])
+        t["pred0_b"] = sdd["prediction.0.bias"].contiguous()
+        t["pred1_w"] = ops.pack_conv_weight(sdd["prediction.2.weight"])
+        t["pred1_b"] = sdd["prediction.2.bias"].contiguous()
+        w3 = sdd["prediction.4.weight"]                              # (2, 64, 1)
+        if w3.shape[0] != 2:
+            raise ValueError("MULTI_OFFSET != 1 is not supported (reference default is 1)")
+        t["pred2_w"] = w3[:, :, 0].t().contiguous()                  # (64, 2)
+        t["pred2_b"] = sdd["prediction.4.bias"].contiguous()
+        self.tensors = t
+        self.device = dev
+        s = SnakeNetStruct()
+        for name in ("head_w", "head_b", "head_scale", "head_shift", "fusion_w", "fusion_b",
+                     "pred0_wg", "pred0_ws", "pred0_b", "pred1_w", "pred1_b", "pred2_w", "pred2_b"):
+            setattr(s, name, t[name].data_ptr())
+        for i in range(7):
+            s.res_w[i] = t["res%d_w" % i].data_ptr()
+            s.res_b[i] = t["res%d_b" % i].data_ptr()
+            s.res_scale[i] = t["res%d_scale" % i].data_ptr()
+            s.res_shift[i] = t["res%d_shift" % i].data_ptr()
+            s.dilation[i] = self.dilations[i]
+        s.feat_channels = self.feature_dim - 2
+        self.struct = s
+
+
+def sub_state_dict(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+class ContourDeformer:
+    """Iterative contour deformation on one GPU.
+
+    nets: one SnakeNetWeights per iteration (deformer0..2, snake_head.py:621-630).
+    padding: "reflection" (DANCE, snake_head.py:1570) or "zeros" (Dsnake, dsnake_head.py:690).
+    de_loc_type: "derange" | "demean" | "demin" (snake_head.py:1587-1610).
+    individual_scale: tanh(offset) * (w,h) (snake_head.py:1702-1703).
+    attention: features carry the attention map; offsets of iterations >= 1 are multiplied
+               by the attention sampled at the iteration's input vertices (1643-1645, 1705-1707).
+    """
+
+    MAX_CHUNK = 4096      # contours per kernel sequence: bounds the workspace
+
+    def __init__(self, nets, padding="reflection", de_loc_type="derange", individual_scale=True,
+                 attention=True, fused_head=True):
+        self.nets = list(nets)
+        self.padding = ops.PAD_REFLECTION if padding == "reflection" else ops.PAD_ZEROS
+        self.deloc = ops.DELOC[de_loc_type]
+        self.individual_scale = bool(individual_scale)
+        self.attention = bool(attention)
+        self.fused_head = bool(fused_head)
+        self._ws = None
+
+    def _workspace(self, n, v, device):
+        need = lib().dance_snake_workspace_bytes(n, v)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        return self._ws, need
+
+    def prepare_features(self, features):
+        """(B, [1+]C, Hf, Wf) NCHW (channel 0 = attention map when `attention`) ->
+        (feat NHWC (B,Hf,Wf,C), att (B,Hf,Wf) or None).  The split replaces
+        snake_head.py:1812-1814; the re-concatenation of :1824 never happens."""
+        return ops.nchw_to_nhwc(features, 1 if self.attention else 0)
+
+    def evolve(self, it, feat, att, locations, image_idx, whs, *, use_att, clip_first, clip_max,
+               x_in=None, out=None, stage_events=None):
+        """One iteration with deformer `it` (RefineNet.evolve, snake_head.py:1624-1713).
+        stage_events: optional list of EVOLVE_EVENTS recorded torch.cuda.Event(enable_timing)
+        (single-chunk calls only) -- bench instrumentation."""
+        net = self.nets[it]
+        n, v, _ = locations.shape
+        dev = locations.device
+        locations = locations.contiguous()
+        if out is None:
+            out = torch.empty((n, v, 2), dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        b, hf, wf, c = feat.shape
+        if c != net.feature_dim - 2:
+            raise RuntimeError("feature channels %d do not match the snake's %d" % (c, net.feature_dim - 2))
+        if self.individual_scale and whs is None:
+            raise RuntimeError("individual_scale needs whs")
+        if image_idx is not None and image_idx.dtype != torch.int32:
+            image_idx = image_idx.to(torch.int32)
+        chunk = min(n, self.MAX_CHUNK)
+        ws, need = self._workspace(chunk, v, dev)
+        ev = None
+        if stage_events is not None:
+            if n > chunk or len(stage_events) != EVOLVE_EVENTS:
+                raise RuntimeError("stage events need a single-chunk call and %d events" % EVOLVE_EVENTS)
+            ev = (ctypes.c_void_p * EVOLVE_EVENTS)(*[e.cuda_event for e in stage_events])
+        with torch.cuda.device(dev):
+            stream = current_stream()
+            for n0 in range(0, n, chunk):
+                nb = min(chunk, n - n0)
+                check(lib().dance_snake_evolve(
+                    ctypes.byref(net.struct), ptr(feat), ptr(att), ptr(locations[n0:]),
+                    ptr(image_idx[n0:]) if image_idx is not None else None,
+                    ptr(whs[n0:]) if whs is not None else None,
+                    ptr(x_in[n0:]) if x_in is not None else None, ptr(out[n0:]), ptr(ws), need,
+                    nb, v, b, hf, wf, self.padding, self.deloc, int(self.individual_scale),
+                    int(use_att), int(clip_first and n0 == 0), float(clip_max[0]), float(clip_max[1]),
+                    int(self.fused_head), ev, stream), "snake_evolve")
+        return out
+
+    def deform(self, features, init_contours, image_idx, image_sizes, whs, layout="nchw",
+               stage_events=None):
+        """features: NCHW (B,[1+]C,Hf,Wf) as the reference's evolve loop sees it after
+        `bottom_out` (+ attention map in channel 0), or with layout="nhwc" the pair
+        (feat NHWC, att) from `prepare_features`.
+        init_contours (N,V,2) f32 image px; image_idx (N,) float/int tensor or None;
+        image_sizes: (h,w) when image_idx is None, else list of (h,w);
+        whs (N,2) box sizes.  Returns [contours after iteration 0, 1, 2] (N,V,2).
+
+        Reference driver: snake_head.py:1822-1862 (single image) / 1969-1995 (batched).
+        `clip_locations` (1715-1727) is reproduced as it behaves: with image_idx None only
+        contour 0 is clamped to the image; with a tensor image_idx nothing is clamped."""
+        if layout == "nchw":
+            feat, att = self.prepare_features(features)
+        else:
+            feat, att = features
+        locations = init_contours.contiguous().float()
+        if whs is not None:
+            whs = whs.contiguous().float()
+        idx = None
+        if image_idx is not None:
+            idx = image_idx.to(torch.int32).contiguous()
+        clip_first = image_idx is None
+        clip_max = (image_sizes[1] - 1, image_sizes[0] - 1) if clip_first else (0.0, 0.0)
+        preds, cur = [], locations
+        for i in range(len(self.nets)):
+            cur = self.evolve(i, feat, att, cur, idx, whs, use_att=(self.attention and i > 0),
+                              clip_first=clip_first, clip_max=clip_max,
+                              stage_events=None if stage_events is None else stage_events[i])
+            preds.append(cur)
+        return preds

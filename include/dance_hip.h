@@ -1,0 +1,188 @@
+/*
+ * dance_hip.h -- C ABI of libdance_hip.so, the MI355X (gfx950) implementation of DANCE's
+ * contour-deformation hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.cuda memory) unless its name
+ *     ends in _host; tensors are dense, row-major, shapes as written;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are
+ *     enqueued on it and the call returns without synchronising; no entry point
+ *     allocates, frees or copies (safe under graph capture) -- scratch comes in through
+ *     explicit workspace arguments;
+ *   - return value: 0 (hipSuccess) or a hipError_t; argument errors return
+ *     hipErrorInvalidValue (1) before anything is enqueued; dance_last_error() has the
+ *     text;
+ *   - "reference" citations are into lkevinzc/dance: the op each entry point replaces.
+ */
+#ifndef DANCE_HIP_H_
+#define DANCE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- library ---------- */
+int dance_abi_version(void);                 /* bumps when a signature changes          */
+const char *dance_last_error(void);          /* thread-local text of the last failure   */
+/* Fills CU count and LDS bytes per workgroup of the current device (host out-params). */
+int dance_device_info(int *cu_count_host, int *lds_bytes_host);
+
+/* ------------------------------------------------------- extreme_utils (L6) -------- */
+/* reference: core/layers/extreme_utils/src/utils.cu:114-212 (pybind `collect_extreme_point`,
+ * utils.cpp:5).  ext_hm (b,4,h,w) f32, bbox (b,n,4) i64, radius (b,n) i64,
+ * vote (b,h,w,2) f32, ct (b,n,2) f32 -> extreme_point (b,n,4,2) i64 (every element
+ * written).  Pixels outside the map, which the reference reads unchecked, are skipped. */
+int dance_collect_extreme_point(const float *ext_hm, const int64_t *bbox,
+                                const int64_t *radius, const float *vote, const float *ct,
+                                int64_t *extreme_point, int b, int n, int h, int w,
+                                void *stream);
+
+/* reference: utils.cu:215-300 (`calculate_edge_num`, utils.cpp:6).  Mutates edge_num
+ * (b,n,orig_p_num) i64 in place; edge_num_sum (b,n) i64; edge_idx_sort (b,n,orig_p_num). */
+int dance_calculate_edge_num(int64_t *edge_num, const int64_t *edge_num_sum,
+                             const int64_t *edge_idx_sort, int b, int n, int orig_p_num,
+                             int64_t p_num, void *stream);
+
+/* reference: utils.cu:303-374 (`calculate_wnp`, utils.cpp:7).  weight (b,n,p_num,1) f32
+ * and ind (b,n,p_num,2) i64: every slot is written (slots no edge covers get 0, which is
+ * what the reference's zero-initialised outputs hold there). */
+int dance_calculate_wnp(const int64_t *edge_num, const int64_t *edge_start_idx,
+                        float *weight, int64_t *ind, int b, int n, int orig_p_num,
+                        int p_num, void *stream);
+
+/* reference: utils.cu:377-440 (`roll_array`, utils.cpp:8).  array (b,n,d) f32,
+ * step (b) i64 -> new_array (b,n,d): new[b][(i+step[b]) mod n] = array[b][i]. */
+int dance_roll_array(const float *array, const int64_t *step, float *new_array, int b,
+                     int n, int d, void *stream);
+
+/* ------------------------------------------------- contour initialisation (a11-a15) - */
+enum {
+    DANCE_POLY_RAW = 0,      /* src = polygons (n,e,2)                                  */
+    DANCE_POLY_BOX = 1,      /* src = boxes (n,4) xyxy -> 4 corners, snake_head.py:870-879 */
+    DANCE_POLY_QUAD = 2,     /* src = boxes (n,4) -> edge mid-points, dsnake_head.py:501-517 */
+    DANCE_POLY_OCTAGON = 3   /* src = extreme points (n,4,2) -> 12-gon, snake_head.py:796-830 */
+};
+/* reference: RefineNet.uniform_upsample (snake_head.py:764-794) fused with its two
+ * kernels and with the polygon builders above.  out (n,p_num,2) f32,
+ * edge_start_idx (n,e) i64 (e = 4, 4, 12 for BOX, QUAD, OCTAGON; may be NULL),
+ * status (n) i32: 1 where the counts could not be brought to p_num (the reference
+ * asserts, snake_head.py:782); such rows are zero-filled.  e <= 64, p_num <= 4096. */
+int dance_uniform_upsample(int kind, const float *src, int n, int e, int p_num, float *out,
+                           int64_t *edge_start_idx, int32_t *status, void *stream);
+
+/* ----------------------------------------------------------------- layout ---------- */
+/* (b, c_total, hw) NCHW -> feat (b, hw, c_total - att_channels) NHWC and, when
+ * att_channels == 1, channel 0 -> att (b, hw).  Replaces the split at
+ * snake_head.py:1812-1814 / 1949-1951 plus the layout change the gather wants. */
+int dance_nchw_to_nhwc(const float *src, float *feat, float *att, int b, int c_total,
+                       int att_channels, int hw, void *stream);
+
+/* ------------------------------------------------------------ gather (a1-a3) ------- */
+enum { DANCE_PAD_ZEROS = 0, DANCE_PAD_REFLECTION = 1 };
+enum { DANCE_DELOC_DERANGE = 0, DANCE_DELOC_DEMEAN = 1, DANCE_DELOC_DEMIN = 2,
+       DANCE_DELOC_NONE = 3 };
+/* reference: RefineNet.get_locations_feature (snake_head.py:1542-1578) / DsnakeHead's
+ * (dsnake_head.py:670-695) + de_location (1580-1614 / 697-708) + the concat of
+ * evolve (1643-1652).
+ *   feat (b,hf,wf,c) f32 NHWC, c % 4 == 0; att (b,hf,wf) or NULL; loc (n,v,2) image px;
+ *   image_idx (n) i32 or NULL (= image b-1, what the reference's loop leaves behind);
+ *   x_out (n, c + (deloc != NONE ? 2 : 0), v) channel-major; att_out (n,v) or NULL. */
+int dance_gather_features(const float *feat, const float *att, const float *loc,
+                          const int32_t *image_idx, float *x_out, float *att_out, int n,
+                          int v, int b, int hf, int wf, int c, int padding_mode,
+                          int deloc_type, void *stream);
+
+/* ------------------------------------------------------- snake blocks (a4-a6) ------ */
+enum {
+    DANCE_EP_RELU = 1,      /* y = max(y, 0) after bias                                 */
+    DANCE_EP_AFFINE = 2,    /* y = y*scale[o] + shift[o]  (eval BatchNorm1d after ReLU) */
+    DANCE_EP_RESIDUAL = 4,  /* y += residual[n][o][v]                                   */
+    DANCE_EP_ROWINIT = 8,   /* accumulator starts at rowinit[n][o] instead of bias[o]   */
+    DANCE_EP_MAXV = 16      /* store max over v into y (n,cout) instead of (n,cout,v)   */
+};
+/* Circular dilated Conv1d over the vertex ring as an fp32 MFMA implicit GEMM:
+ *   y[n][o][v] = ep( bias[o] + sum_{t<taps} sum_{c<cin} w[t][c][o] * x[n][c][(v+(t-taps/2)*dilation) mod V] )
+ * reference: DilatedCircularConv (snake_head.py:92-116) + SnakeBlock (140-153) + the
+ * residual add of _SnakeNet.forward (266); taps = 1 gives the k=1 Conv1d's (fusion 249,
+ * prediction 252-258, Dsnake fuse dsnake_head.py:242).
+ *   x: channel-major (cin, v) per contour, contour stride x_stride floats;
+ *   w_packed (taps, cin_pad, cout) f32 with cin_pad = cin rounded up to 16, zero rows;
+ *   y: (cout, v) per contour with contour stride y_stride floats, or (n,cout) for MAXV;
+ *   residual: same layout/stride as y.  v % 4 == 0, 16 <= v <= 256, cout % 32 == 0. */
+int dance_circconv(const float *x, int64_t x_stride, const float *w_packed,
+                   const float *bias, const float *scale, const float *shift,
+                   const float *residual, const float *rowinit, float *y, int64_t y_stride,
+                   int n, int v, int cin, int cout, int taps, int dilation, int flags,
+                   void *stream);
+
+/* Fused first block: gather (as dance_gather_features) straight into LDS, then the head
+ * SnakeBlock (cin = c + 2, taps 9, dilation 1, ReLU + affine).  reference: evolve
+ * (snake_head.py:1639-1652) + _SnakeNet.head (263).  Also writes att_out (n,v). */
+int dance_gather_circconv_head(const float *feat, const float *att, const float *loc,
+                               const int32_t *image_idx, const float *w_packed,
+                               const float *bias, const float *scale, const float *shift,
+                               float *y, int64_t y_stride, float *att_out, int n, int v,
+                               int b, int hf, int wf, int c, int cout, int padding_mode,
+                               int deloc_type, void *stream);
+
+/* h[n][o] = bias[o] + sum_g wg[g][o] * g[n][g]: the vertex-invariant input columns of a
+ * k=1 Conv1d folded into a per-contour row constant (used through DANCE_EP_ROWINIT).
+ * reference: the expanded global state fed to prediction[0] (snake_head.py:272-282) and
+ * the expanded centre feature fed to Dsnake's fuse (dsnake_head.py:723-729).
+ *   g (n,g_dim), wg (g_dim,cout), bias (cout) -> h (n,cout); g_dim <= 1024. */
+int dance_row_constant(const float *g, const float *wg, const float *bias, float *h, int n,
+                       int g_dim, int cout, void *stream);
+
+/* ------------------------------------------------ offset head + update (a6 tail-a8) - */
+/* y[n][v][:] = loc + scale(tanh?)(w3^T p2 + b3) * att, optional clamp of contour 0.
+ * reference: prediction[4] (snake_head.py:257), evolve tail 1702-1711, clip_locations
+ * 1715-1727 (clip_first: only contour 0 is clamped -- the reference's behaviour when
+ * image_idx is None; with a tensor image_idx it clamps nothing).
+ *   p2 (n,64,v) f32; w3 (64,2); b3 (2); loc (n,v,2); whs (n,2) or NULL (no tanh scaling);
+ *   att (n,v) or NULL; out (n,v,2); clip_x_max = image width - 1, clip_y_max = height - 1. */
+int dance_offset_update(const float *p2, int64_t p2_stride, const float *w3, const float *b3,
+                        const float *loc, const float *whs, const float *att, float *out,
+                        int n, int v, int cmid, int clip_first, float clip_x_max,
+                        float clip_y_max, void *stream);
+
+/* ------------------------------------------------------- one whole iteration ------- */
+/* Device pointers to one _SnakeNet's packed parameters (dance_amd/snake.py packs them
+ * from a reference state-dict).  All f32. */
+typedef struct dance_snake_net {
+    const float *head_w, *head_b, *head_scale, *head_shift;           /* (9,cin_pad,128)      */
+    const float *res_w[7], *res_b[7], *res_scale[7], *res_shift[7];   /* (9,128,128)          */
+    const float *fusion_w, *fusion_b;                                 /* (1,1024,256)         */
+    const float *pred0_wg;                                            /* (256,256) [g][o]     */
+    const float *pred0_ws, *pred0_b;                                  /* (1,1024,256)         */
+    const float *pred1_w, *pred1_b;                                   /* (1,256,64)           */
+    const float *pred2_w, *pred2_b;                                   /* (64,2), (2)          */
+    int dilation[7];
+    int feat_channels;                                                /* c (256)              */
+} dance_snake_net;
+
+/* Bytes of workspace one dance_snake_evolve call needs for n contours of v vertices. */
+int64_t dance_snake_workspace_bytes(int n, int v);
+
+/* One evolve step (reference: RefineNet.evolve snake_head.py:1624-1713 /
+ * DsnakeHead.evolve dsnake_head.py:748-765): gather -> snake net -> offset update.
+ *   individual_scale: tanh(off) * whs (whs required); use_att: multiply by the sampled
+ *   attention (att map required); x_in: optional precomputed (n, c+2, v) input that
+ *   replaces the gather (Dsnake init path), else NULL;
+ *   stage_events_host: NULL, or DANCE_EVOLVE_EVENTS hipEvent_t handles recorded on `stream`
+ *   before the first kernel and after each stage (head | res0..6 | fusion | row constant |
+ *   prediction[0] | prediction[2] | offset update) -- timing instrumentation for bench.py. */
+#define DANCE_EVOLVE_EVENTS 14
+int dance_snake_evolve(const dance_snake_net *net_host, const float *feat, const float *att,
+                       const float *loc, const int32_t *image_idx, const float *whs,
+                       const float *x_in, float *out, void *workspace,
+                       int64_t workspace_bytes, int n, int v, int b, int hf, int wf,
+                       int padding_mode, int deloc_type, int individual_scale, int use_att,
+                       int clip_first, float clip_x_max, float clip_y_max, int fused_head,
+                       void **stage_events_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANCE_HIP_H_ */

@@ -147,7 +147,9 @@ void ref_calculate_edge_num(int64_t *edge_num, const int64_t *edge_num_sum,
         }
         int64_t surplus = sum - p_num;
         int k = 0;
-        while (surplus > 0) {
+        /* the reference's `while (pass_num > 0)` runs off the array when every edge is
+         * already down to one point (E > p_num: undefined behaviour there); stop at E */
+        while (surplus > 0 && k < E) {
             int64_t e = order[k];
             if (cnt[e] > surplus) {
                 cnt[e] -= surplus;

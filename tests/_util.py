@@ -1,0 +1,80 @@
+"""Shared helpers for the test-suite (the only place besides bench/smoke that may import oracle/)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REL_TOL = 1e-4      # north_star: fp32 vertex coordinates within 1e-4 relative per iteration
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: torch.from_numpy(np.array(z[k])) for k in z.files}
+
+
+def rel_err(a, b, floor=1.0):
+    """max |a-b| / max(|b|, floor) with NaNs required at identical places."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.equal(torch.isnan(a), torch.isnan(b)), "NaN pattern differs"
+    a, b = torch.nan_to_num(a), torch.nan_to_num(b)
+    if a.numel() == 0:
+        return 0.0
+    return float(((a - b).abs() / b.abs().clamp_min(floor)).max())
+
+
+def coord_rel_err(a, b):
+    """relative error on vertex coordinates: |a-b| / max(|b|, 1 px)."""
+    return rel_err(a, b, floor=1.0)
+
+
+def dance_state_dict(seed, num_sampling=128, **cfg_over):
+    """Seeded synthetic weights in the reference's key order, via the drop-in module's
+    own state-dict (keys/shapes/order are checked against the fixture checksum)."""
+    from dance_amd import config, modules, synthetic
+
+    cfg = config.dance_r50(num_sampling=num_sampling, num_convs=0, **cfg_over)
+    net = modules.RefineNet(cfg)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    ck = synthetic.fill_state_dict_(sd, seed)
+    return cfg, sd, ck
+
+
+def dsnake_state_dict(seed):
+    from dance_amd import config, modules, synthetic
+
+    cfg = config.dsnake_r50(num_convs=0)
+    net = modules.DsnakeHead(cfg)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    ck = synthetic.fill_state_dict_(sd, seed)
+    return cfg, sd, ck
+
+
+class FakeBoxes:
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    def clip(self, box_size):
+        h, w = box_size
+        self.tensor[:, 0].clamp_(min=0, max=w)
+        self.tensor[:, 1].clamp_(min=0, max=h)
+        self.tensor[:, 2].clamp_(min=0, max=w)
+        self.tensor[:, 3].clamp_(min=0, max=h)
+
+
+class FakeInstances:
+    """Duck-typed detectron2 Instances."""
+
+    def __init__(self, image_size, **fields):
+        object.__setattr__(self, "_fields", set())
+        object.__setattr__(self, "image_size", image_size)
+        for k, v in fields.items():
+            setattr(self, k, v)
+
+    def __setattr__(self, k, v):
+        self._fields.add(k)
+        object.__setattr__(self, k, v)
+
+    def has(self, name):
+        return name in self._fields

@@ -1,0 +1,141 @@
+"""GPU: the four extreme_utils ops and the fused resampler against the C oracle and the
+golden vectors -- integer / index outputs and resampled coordinates bit-exact."""
+import pytest
+import torch
+
+from _util import golden
+from dance_amd import extreme_utils as ext
+from dance_amd import ops
+from oracle import extreme_utils_ref as cref
+from test_oracle_golden import RESAMPLER_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _collect_inputs(b, n, h, w, seed, int_scores=False):
+    g = torch.Generator().manual_seed(seed)
+    hm = torch.rand((b, 4, h, w), generator=g)
+    if int_scores:                      # many exact ties -> exercises first-max-in-scan-order
+        hm = torch.floor(hm * 4)
+    vote = torch.randn((b, h, w, 2), generator=g)
+    x0 = torch.randint(0, w // 2, (b, n), generator=g)
+    y0 = torch.randint(0, h // 2, (b, n), generator=g)
+    x1 = x0 + torch.randint(0, w // 2, (b, n), generator=g)
+    y1 = y0 + torch.randint(0, h // 2, (b, n), generator=g)
+    bbox = torch.stack([x0, y0, x1, y1], dim=2).long()
+    radius = torch.randint(0, 6, (b, n), generator=g).long()
+    ct = torch.stack([(x0 + x1) / 2.0, (y0 + y1) / 2.0], dim=2).float()
+    # votes: half of the pixels point exactly at some centre, the rest are random
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    to_c = torch.stack([ct[:, 0, 0][:, None, None] - xs, ct[:, 0, 1][:, None, None] - ys], dim=-1)
+    mask = torch.rand((b, h, w, 1), generator=g) < 0.5
+    vote = torch.where(mask, to_c, vote).contiguous()
+    return hm, bbox, radius, vote, ct
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 5, 5), (2, 7, 40, 56), (3, 33, 100, 152)])
+@pytest.mark.parametrize("ties", [False, True])
+def test_collect_extreme_point(device, shape, ties):
+    b, n, h, w = shape
+    inp = _collect_inputs(b, n, h, w, seed=b * 100 + n, int_scores=ties)
+    want = cref.collect_extreme_point(*inp)
+    got = ext.collect_extreme_point(*[t.to(device) for t in inp])
+    assert got.dtype == torch.int64 and got.shape == (b, n, 4, 2)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_collect_extreme_point_known_answer_and_errors(device):
+    h = w = 5
+    hm = torch.zeros((1, 4, h, w))
+    hm[0, 0, 0, 3], hm[0, 1, 1, 0], hm[0, 2, 4, 1], hm[0, 3, 2, 4] = 2.0, 3.0, 5.0, 1.0
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    vote = torch.stack([2.0 - xs, 2.0 - ys], dim=-1)[None].contiguous()
+    bbox = torch.tensor([[[0, 0, 4, 4]]], dtype=torch.int64)
+    radius = torch.tensor([[1]], dtype=torch.int64)
+    ct = torch.tensor([[[2.0, 2.0]]])
+    args = [t.to(device) for t in (hm, bbox, radius, vote, ct)]
+    assert ext.collect_extreme_point(*args).cpu().tolist() == [[[[3, 0], [0, 1], [1, 4], [4, 2]]]]
+    args[3] = -args[3]
+    assert ext.collect_extreme_point(*args).cpu().tolist() == [[[[2, 0], [0, 2], [2, 4], [4, 2]]]]
+    with pytest.raises(RuntimeError, match="ext_hm must be a CUDA tensor"):
+        ext.collect_extreme_point(hm, *args[1:])
+    with pytest.raises(RuntimeError, match="same batch size"):
+        ext.collect_extreme_point(args[0], args[1].repeat(2, 1, 1), *args[2:])
+    # empty: n = 0
+    out = ext.collect_extreme_point(args[0], args[1][:, :0], args[2][:, :0], args[3], args[4][:, :0])
+    assert out.shape == (1, 0, 4, 2)
+
+
+@pytest.mark.parametrize("E,p", [(4, 128), (12, 128), (12, 40), (7, 196)])
+def test_edge_num_and_wnp(device, E, p):
+    g = torch.Generator().manual_seed(E * 1000 + p)
+    b, n = 2, 257
+    length = torch.rand((b, n, E), generator=g) ** 3 + 1e-3
+    en = torch.round(length * p / length.sum(2, keepdim=True)).long().clamp(min=1)
+    en[0, 0] = 1                                   # big deficit
+    en[0, 1] = p                                   # big surplus
+    sort = torch.argsort(en, dim=2, descending=True, stable=True)
+    want = en.clone()
+    cref.calculate_edge_num(want, want.sum(2), sort, p)
+    got = en.clone().to(device)
+    ret = ext.calculate_edge_num(got, got.sum(2), sort.to(device), p)
+    assert ret is None
+    assert torch.equal(got.cpu(), want)
+    assert torch.all(want.sum(2) == p)
+    start = torch.cumsum(want, 2) - want
+    w_want, i_want = cref.calculate_wnp(want, start, p)
+    w_got, i_got = ext.calculate_wnp(got, start.to(device), p)
+    assert w_got.shape == (b, n, p, 1) and i_got.shape == (b, n, p, 2)
+    assert torch.equal(w_got.cpu(), w_want) and torch.equal(i_got.cpu(), i_want)
+    with pytest.raises(RuntimeError, match="edge_num must be contiguous"):
+        ext.calculate_edge_num(got.transpose(1, 2).contiguous().transpose(1, 2), got.sum(2), sort.to(device), p)
+    with pytest.raises(RuntimeError, match="edge_num must be a CUDA tensor"):
+        ext.calculate_edge_num(en, en.sum(2), sort, p)
+
+
+@pytest.mark.parametrize("shape", [(1, 6, 2), (3, 128, 2), (5, 37, 9), (2, 1, 1)])
+def test_roll_array(device, shape):
+    b, n, d = shape
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(shape, generator=g)
+    step = torch.randint(-3 * n, 3 * n, (b,), generator=g).long()
+    want = cref.roll_array(a, step)
+    got = ext.roll_array(a.to(device), step.to(device))
+    assert torch.equal(got.cpu(), want)
+    for i in range(b):
+        assert torch.equal(want[i], torch.roll(a[i], int(step[i]), 0))
+    with pytest.raises(RuntimeError, match="step must have the same batch size"):
+        ext.roll_array(a.to(device), step[:0].to(device))
+
+
+def test_fused_resampler_golden_bit_exact(device):
+    g = golden("g1_resampler")
+    for name, ps in RESAMPLER_CASES:
+        for p in ps:
+            pts, start = ops.uniform_upsample(g[name + "_poly"].to(device), p)
+            assert torch.equal(start.cpu(), g["%s_p%d_start" % (name, p)]), (name, p)
+            assert torch.equal(pts.cpu(), g["%s_p%d_points" % (name, p)]), (name, p)
+    # polygon builders fused in: octagon from extreme points, boxes, quadrangles
+    pts, start = ops.uniform_upsample(g["octagon_ext"].to(device), 128, kind=ops.POLY_OCTAGON)
+    assert torch.equal(pts.cpu(), g["octagon_p128_points"]) and torch.equal(start.cpu(), g["octagon_p128_start"])
+
+
+def test_fused_resampler_builders_and_large(device):
+    from dance_amd import synthetic
+    from oracle import snake_ref
+    boxes = synthetic.make_boxes(3000, 800, 1216, seed=5)
+    for kind, poly, p in ((ops.POLY_BOX, snake_ref.box_polygon(boxes), 128),
+                          (ops.POLY_BOX, snake_ref.box_polygon(boxes), 196),
+                          (ops.POLY_QUAD, snake_ref.quadrangle(boxes), 40)):
+        want_pts, want_start, status = cref.uniform_upsample_fused(poly, p)
+        assert int(status.sum()) == 0
+        pts, start = ops.uniform_upsample(boxes.to(device), p, kind=kind)
+        assert torch.equal(pts.cpu(), want_pts) and torch.equal(start.cpu(), want_start)
+    # reference-style call through the 4-D (1,N,E,2) layout + empty input
+    pts, start = ops.uniform_upsample(snake_ref.box_polygon(boxes)[None].to(device), 128)
+    assert pts.shape == (3000, 128, 2)
+    pts, start = ops.uniform_upsample(boxes[:0].to(device), 128, kind=ops.POLY_BOX)
+    assert pts.shape == (0, 128, 2)
+    # E > p_num cannot be satisfied: flagged instead of the reference's out-of-bounds walk
+    with pytest.raises(AssertionError):
+        ops.uniform_upsample(torch.rand((2, 12, 2)).to(device), 5)

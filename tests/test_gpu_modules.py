@@ -1,0 +1,86 @@
+"""GPU: the drop-in modules behind the reference's forward(features, pred_instances, targets)."""
+import pytest
+import torch
+
+from _util import REL_TOL, FakeBoxes, FakeInstances, coord_rel_err, dance_state_dict, golden
+from dance_amd import config, modules, synthetic
+from dance_amd.structures import ExtremePoints
+from test_oracle_golden import dance_case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _module(cfg, sd, device):
+    net = modules.RefineNet(cfg)
+    net.load_state_dict(sd)
+    return net.to(device).eval()
+
+
+def test_refinenet_single_test_box(device):
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("single_box_v196")
+    net = _module(cfg, sd, device)
+    inst = FakeInstances(sizes, pred_boxes=FakeBoxes(g["boxes"][0].to(device)))
+    with torch.no_grad():
+        res, losses = net(feats.to(device), [inst], None)
+    assert losses == {} and len(res) == 1
+    assert res[0].pred_polys.tensor.shape == g["pred2"].shape
+    assert coord_rel_err(res[0].pred_polys.tensor, g["pred2"]) < REL_TOL
+    with pytest.raises(NotImplementedError):
+        net.train()(feats.to(device), [inst], None)
+
+
+def test_refinenet_single_test_octagon(device):
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("single_octagon_v128")
+    cfg.initial = "octagon"
+    net = _module(cfg, sd, device)
+    ext = ExtremePoints(g["ext_points"][0].clone().to(device))
+    inst = FakeInstances(sizes, pred_boxes=FakeBoxes(g["boxes"][0].to(device)), ext_points=ext)
+    with torch.no_grad():
+        res, _ = net(feats.to(device), [inst], None)
+    assert coord_rel_err(res[0].pred_polys.tensor, g["pred2"]) < REL_TOL     # NaN rows included
+    # the in-place fit_to_box pulled the stray point back inside its box
+    assert float(ext.tensor[1, 0, 0]) >= float(ext.tensor[1, 1, 0])
+    # an image without detections returns the instances untouched
+    empty = FakeInstances(sizes, pred_boxes=FakeBoxes(torch.zeros((0, 4), device=device)))
+    cfg.initial = "box"
+    res, _ = _module(cfg, sd, device)(feats.to(device), [empty], None)
+    assert res[0] is empty and not empty.has("pred_polys")
+
+
+def test_refinenet_batched(device):
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("batched_box_v128")
+    cfg.vis_path = True
+    net = _module(cfg, sd, device)
+    insts = [FakeInstances(sizes[i], pred_boxes=FakeBoxes(g["boxes"][i].to(device))) for i in range(2)]
+    with torch.no_grad():
+        res, _ = net(feats.to(device), insts, None)
+    got = torch.cat([r.pred_polys.tensor for r in res])
+    assert coord_rel_err(got, g["pred2"]) < REL_TOL
+    assert res[0].pred_path.shape == (3, 4, 128, 2)
+
+
+def test_bottom_out_channels_last_feeds_the_gather(device):
+    """with bottom_out in place (NUM_CONVS=2) the torch convs run channels_last and their
+    output is consumed without a layout pass; result = the oracle on the same features."""
+    from oracle import snake_ref
+    cfg = config.dance_r50(num_sampling=128, num_convs=2)
+    net = modules.RefineNet(cfg)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    synthetic.fill_state_dict_(sd, 99)
+    assert "bottom_out.0.norm.weight" in sd and "bottom_out.1.weight" in sd and "bottom_out.0.bias" not in sd
+    net.load_state_dict(sd)
+    net = net.to(device).eval()
+    feats = synthetic.make_features(1, 256, 24, 32, 5).to(device)
+    boxes = synthetic.make_boxes(4, 96, 128, 6, r_min=6, r_max=30)
+    inst = FakeInstances((96, 128), pred_boxes=FakeBoxes(boxes.clone().to(device)))
+    with torch.no_grad():
+        res, _ = net(feats, [inst], None)
+        x = feats[:, 1:]
+        for conv in net.bottom_out:
+            x = conv(x)
+        full = torch.cat([feats[:, :1], x], dim=1).cpu()
+    init, _ = snake_ref.uniform_upsample(snake_ref.box_polygon(boxes)[None], 128)
+    b = boxes.clone()
+    whs = torch.stack([b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1)
+    want = snake_ref.dance_deform(sd, full, init, None, (96, 128), whs)
+    assert coord_rel_err(res[0].pred_polys.tensor, want[-1]) < REL_TOL

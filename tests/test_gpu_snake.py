@@ -1,0 +1,188 @@
+"""GPU: snake blocks, whole snake nets, and the 3-iteration deformation chains against the
+golden vectors (reference outputs) and the oracle -- fp32 vertex coordinates within 1e-4
+relative per iteration (north_star), intermediate activations within 1e-4 of their scale."""
+import pytest
+import torch
+
+from _util import REL_TOL, coord_rel_err, dance_state_dict, dsnake_state_dict, golden, rel_err
+from dance_amd import modules, ops, snake, synthetic
+from oracle import snake_ref
+from test_oracle_golden import DANCE_CASES, dance_case_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _block_on_gpu(sd, x, d, device, cin, residual=False):
+    w = ops.pack_conv_weight(sd["conv.fc.weight"].to(device))
+    scale, shift = snake._fold_bn({k: v.to(device) for k, v in sd.items()}, "norm.")
+    xg = x.to(device)
+    return ops.circconv(xg, w, sd["conv.fc.bias"].to(device), cin=cin, dilation=d, scale=scale,
+                        shift=shift, relu=True, residual=xg if residual else None)
+
+
+def test_snake_block_golden(device):
+    g = golden("g3_snake_block")
+    for tag, cin, d in (("c128_d1_v128", 128, 1), ("c128_d2_v196", 128, 2), ("c128_d4_v40", 128, 4),
+                        ("c258_d1_v128", 258, 1), ("c128_d4_v256", 128, 4)):
+        blk = modules.SnakeBlock(cin, 128)
+        sd = {k: v.clone() for k, v in blk.state_dict().items()}
+        synthetic.fill_state_dict_(sd, int(g[tag + "_seed"]))
+        y = _block_on_gpu(sd, g[tag + "_x"], d, device, cin)
+        scale = float(g[tag + "_y"].abs().max())
+        assert rel_err(y, g[tag + "_y"], floor=scale) < 1e-5, tag
+
+
+@pytest.mark.parametrize("v", [16, 32, 36, 64, 100, 128, 132, 224, 256])
+@pytest.mark.parametrize("d", [1, 2, 4])
+def test_snake_block_shapes_vs_oracle(device, v, d):
+    """ragged ring sizes (not multiples of 32) incl. the smallest the dilation-4 halo allows."""
+    blk = modules.SnakeBlock(128, 128)
+    sd = {k: v_.clone() for k, v_ in blk.state_dict().items()}
+    synthetic.fill_state_dict_(sd, 77 + v + d)
+    x = torch.randn((3, 128, v), generator=torch.Generator().manual_seed(v))
+    want = snake_ref.snake_block(x, sd, "", d) + x
+    got = _block_on_gpu(sd, x, d, device, 128, residual=True)
+    assert rel_err(got, want, floor=float(want.abs().max())) < 1e-5
+
+
+def test_pointwise_rowinit_maxv(device):
+    g = torch.Generator().manual_seed(5)
+    n, v = 5, 128
+    x = torch.randn((n, 1024, v), generator=g)
+    w = torch.randn((256, 1024, 1), generator=g) / 32
+    b = torch.randn((256,), generator=g)
+    want = torch.nn.functional.conv1d(x, w, b)
+    wp = ops.pack_conv_weight(w.to(device))
+    y = ops.circconv(x.to(device), wp, b.to(device), cin=1024)
+    assert rel_err(y, want, floor=float(want.abs().max())) < 1e-5
+    m = ops.circconv(x.to(device), wp, b.to(device), cin=1024, maxv=True)
+    assert rel_err(m, want.max(dim=2)[0], floor=float(want.abs().max())) < 1e-5
+    # row constant = vertex-invariant columns folded out
+    gvec = torch.randn((n, 256), generator=g)
+    wg = torch.randn((256, 256), generator=g) / 16
+    h = ops.row_constant(gvec.to(device), wg.to(device), b.to(device))
+    assert rel_err(h, b[None] + gvec @ wg, floor=1.0) < 1e-5
+    y = ops.circconv(x.to(device), wp, None, cin=1024, rowinit=h, relu=True)
+    want2 = torch.relu(torch.nn.functional.conv1d(x, w) + (b[None] + gvec @ wg)[:, :, None])
+    assert rel_err(y, want2, floor=float(want2.abs().max())) < 1e-5
+    # cout = 64 (two idle waves) and a strided output view
+    w64 = torch.randn((64, 256, 1), generator=g) / 16
+    x256 = torch.randn((n, 256, v), generator=g)
+    out = torch.zeros((n, 66, v), device=device)
+    ops.circconv(x256.to(device), ops.pack_conv_weight(w64.to(device)), b[:64].to(device), cin=256, out=out[:, :64])
+    want3 = torch.nn.functional.conv1d(x256, w64, b[:64])
+    assert rel_err(out[:, :64], want3, floor=float(want3.abs().max())) < 1e-5
+    assert float(out[:, 64:].abs().max()) == 0.0
+
+
+def _net_forward(sd, x, device, whs=None):
+    """whole _SnakeNet through dance_snake_evolve's x_in path: returns raw offsets (N,V,2)."""
+    net = snake.SnakeNetWeights(sd, device)
+    d = snake.ContourDeformer([net], padding="zeros", de_loc_type="demin", individual_scale=False,
+                              attention=False)
+    n, _, v = x.shape
+    loc = torch.zeros((n, v, 2), device=device)
+    feat = torch.zeros((1, 2, 2, 256), device=device)
+    return d.evolve(0, feat, None, loc, None, None, use_att=False, clip_first=False, clip_max=(0, 0),
+                    x_in=x.to(device).contiguous())
+
+
+def test_snake_net_golden(device):
+    g = golden("g4_snake_net")
+    for tag in ("v128", "v196", "v40"):
+        net = modules._SnakeNet(128, 258, (1, 1, 1, 2, 2, 4, 4))
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        synthetic.fill_state_dict_(sd, int(g[tag + "_seed"]))
+        off = _net_forward(sd, g[tag + "_x"], device)            # loc = 0 -> output = offsets
+        want = g[tag + "_y"].permute(0, 2, 1)
+        assert rel_err(off, want, floor=float(want.abs().max())) < 1e-4, tag
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("tag", DANCE_CASES)
+def test_dance_chain_golden(device, tag, fused):
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs(tag)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    d = snake.ContourDeformer(nets, padding="reflection", de_loc_type=cfg.de_loc_type,
+                              individual_scale=cfg.individual_scale, attention=cfg.attention,
+                              fused_head=fused)
+    idx = None if image_idx is None else image_idx.to(device)
+    preds = d.deform(feats.to(device), g["init"].to(device), idx, sizes, g["whs"].to(device))
+    for i in range(3):
+        # (a) the chain as the reference ran it
+        assert coord_rel_err(preds[i], g["pred%d" % i]) < REL_TOL, (tag, i)
+    # (b) per iteration on identical inputs: feed the reference's iteration input
+    for i in range(1, 3):
+        one = d.evolve(i, *d.prepare_features(feats.to(device)), g["pred%d" % (i - 1)].to(device), idx,
+                       g["whs"].to(device), use_att=cfg.attention, clip_first=image_idx is None,
+                       clip_max=(sizes[1] - 1, sizes[0] - 1) if image_idx is None else (0, 0))
+        assert coord_rel_err(one, g["pred%d" % i]) < REL_TOL, (tag, i)
+
+
+def test_clip_quirk(device):
+    """clip_locations (snake_head.py:1715-1727): image_idx None clamps contour 0 only; a
+    tensor image_idx clamps nothing."""
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("single_box_v196")
+    assert image_idx is None
+    p0 = g["pred0"]
+    h, w = sizes
+    assert float(p0[0, :, 0].max()) <= w - 1 and float(p0[0, :, 1].max()) <= h - 1
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    d = snake.ContourDeformer(nets)
+    big = g["whs"].clone() * 40                       # push everything far outside
+    a = d.deform(feats.to(device), g["init"].to(device), None, sizes, big.to(device))[0].cpu()
+    assert float(a[0, :, 0].max()) <= w - 1 and float(a[0, :, 0].min()) >= 0
+    assert float(a[1:, :, 0].max()) > w - 1 or float(a[1:, :, 0].min()) < 0
+    idx = torch.zeros(len(big), device=device)
+    b = d.deform(feats.to(device), g["init"].to(device), idx, [sizes], big.to(device))[0].cpu()
+    assert float(b[0].max()) > w - 1 or float(b[0].min()) < 0        # nothing clamped
+    assert torch.equal(a[1:], b[1:])
+    want = snake_ref.dance_deform(sd, feats, g["init"], None, sizes, big)[0]
+    assert coord_rel_err(a, want) < REL_TOL
+
+
+def test_dsnake_golden(device):
+    from _util import FakeBoxes, FakeInstances
+    g = golden("g6_dsnake")
+    cfg, sd, ck = dsnake_state_dict(int(g["weight_seed"]))
+    hf, wf = int(g["hf"]), int(g["wf"])
+    feats = synthetic.make_features(2, 256, hf, wf, int(g["feat_seed"]), attention=False)
+    head = modules.DsnakeHead(cfg)
+    head.load_state_dict(sd)
+    head = head.to(device).eval()
+    insts = [FakeInstances((hf * 4, wf * 4), pred_boxes=FakeBoxes(g["boxes"][i].to(device))) for i in range(2)]
+    with torch.no_grad():
+        res, losses = head(feats.to(device), insts, None)
+    assert losses == {} and len(res) == 2
+    st = head.last_stages
+    assert torch.equal(st["init"].cpu(), g["init"])                     # resampler: bit-exact
+    assert coord_rel_err(st["exts_raw"], g["exts_raw"]) < REL_TOL
+    assert coord_rel_err(st["exts"], g["exts"]) < REL_TOL
+    assert coord_rel_err(st["octagons"], g["octagons"]) < REL_TOL
+    for i in range(3):
+        assert coord_rel_err(st["preds"][i], g["pred%d" % i]) < REL_TOL, i
+    final = torch.cat([r.pred_polys.tensor for r in res])
+    assert coord_rel_err(final, g["pred2"]) < REL_TOL
+    assert coord_rel_err(torch.cat([r.ext_points.tensor for r in res]), g["exts"]) < REL_TOL
+
+
+def test_deterministic_and_chunked(device):
+    """run twice -> bit-identical; chunking over contours does not change results."""
+    cfg, sd, _ = dance_state_dict(1234, 128)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    feats = synthetic.make_features(3, 256, 50, 76, 11).to(device)
+    boxes = synthetic.make_boxes(41, 200, 304, 12, r_min=8, r_max=60)
+    loc = synthetic.make_circle_contours(boxes, 128).to(device)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).to(device)
+    idx = (torch.arange(41) % 3).float().to(device)
+    d = snake.ContourDeformer(nets)
+    a = d.deform(feats, loc, idx, [(200, 304)] * 3, whs)
+    b = d.deform(feats, loc, idx, [(200, 304)] * 3, whs)
+    d2 = snake.ContourDeformer(nets)
+    d2.MAX_CHUNK = 16
+    c = d2.deform(feats, loc, idx, [(200, 304)] * 3, whs)
+    for i in range(3):
+        assert torch.equal(a[i], b[i]) and torch.equal(a[i], c[i])
+    want = snake_ref.dance_deform(sd, feats.cpu(), loc.cpu(), idx.cpu(), [(200, 304)] * 3, whs.cpu())
+    for i in range(3):
+        assert coord_rel_err(a[i], want[i]) < REL_TOL
