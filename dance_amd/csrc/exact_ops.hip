@@ -330,19 +330,28 @@ __global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *
             py[lane] = src[(poly * E + lane) * 2 + 1];
         }
     } else if (kind == DANCE_POLY_BOX) {
-        // corners (xmax,ymin) (xmin,ymin) (xmin,ymax) (xmax,ymax): snake_head.py:878
+        // corners (xmax,ymin) (xmin,ymin) (xmin,ymax) (xmax,ymax): snake_head.py:878.
+        // Values are loaded first and picked with single-condition selects (a pointer
+        // select under `lane == 0 || lane == 3` was miscompiled by hipcc 7.2).
         if (lane < 4) {
             const float *b = src + poly * 4;
-            px[lane] = (lane == 0 || lane == 3) ? b[2] : b[0];
-            py[lane] = (lane < 2) ? b[1] : b[3];
+            const float x0 = b[0], y0 = b[1], x1 = b[2], y1 = b[3];
+            px[lane] = ((0x9 >> lane) & 1) ? x1 : x0;
+            py[lane] = ((0x3 >> lane) & 1) ? y0 : y1;
         }
     } else if (kind == DANCE_POLY_QUAD) {
         // edge mid-points top, left, bottom, right: dsnake_head.py:506-515
         if (lane < 4) {
             const float *b = src + poly * 4;
-            const float mx = (b[0] + b[2]) / 2.0f, my = (b[1] + b[3]) / 2.0f;
-            px[lane] = lane == 1 ? b[0] : (lane == 3 ? b[2] : mx);
-            py[lane] = lane == 0 ? b[1] : (lane == 2 ? b[3] : my);
+            const float x0 = b[0], y0 = b[1], x1 = b[2], y1 = b[3];
+            const float mx = (x0 + x1) / 2.0f, my = (y0 + y1) / 2.0f;
+            float x = mx, y = my;
+            x = lane == 1 ? x0 : x;
+            x = lane == 3 ? x1 : x;
+            y = lane == 0 ? y0 : y;
+            y = lane == 2 ? y1 : y;
+            px[lane] = x;
+            py[lane] = y;
         }
     } else {
         // 12-gon from extreme points t,l,b,r: snake_head.py:800-830

@@ -53,6 +53,27 @@ def make_features(batch, channels, hf, wf, seed, attention=True):
     return f
 
 
+def make_smooth_features(batch, channels, hf, wf, seed, attention=True, cell=8):
+    """Like make_features but band-limited: white noise on a (hf/cell, wf/cell) lattice,
+    bilinearly interpolated with explicit elementwise ops (bit-reproducible on any CPU).
+    Real FPN features vary slowly at the pixel scale; white-noise features make the
+    3-iteration deformation chaotic (a 0.005 px difference grows ~10x per iteration), which
+    says nothing about an implementation.  Used where a whole chain is compared."""
+    g = torch.Generator().manual_seed(int(seed))
+    c = channels + (1 if attention else 0)
+    gh, gw = hf // cell + 2, wf // cell + 2
+    coarse = torch.randn((batch, c, gh, gw), generator=g)
+    if attention:
+        coarse[:, 0] = torch.rand((batch, gh, gw), generator=g)
+    ys = torch.arange(hf, dtype=torch.float32) / cell
+    xs = torch.arange(wf, dtype=torch.float32) / cell
+    y0, x0 = ys.floor().long(), xs.floor().long()
+    ty, tx = (ys - y0.float())[None, None, :, None], (xs - x0.float())[None, None, None, :]
+    top = coarse[:, :, y0][:, :, :, x0] * (1 - tx) + coarse[:, :, y0][:, :, :, x0 + 1] * tx
+    bot = coarse[:, :, y0 + 1][:, :, :, x0] * (1 - tx) + coarse[:, :, y0 + 1][:, :, :, x0 + 1] * tx
+    return (top * (1 - ty) + bot * ty).contiguous()
+
+
 def make_boxes(n, height, width, seed, r_min=20.0, r_max=100.0):
     """n xyxy boxes with centres in the central 80 % of the image."""
     g = torch.Generator().manual_seed(int(seed))

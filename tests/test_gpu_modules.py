@@ -17,7 +17,7 @@ def _module(cfg, sd, device):
 
 
 def test_refinenet_single_test_box(device):
-    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("single_box_v196")
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("smooth_single_box_v128")
     net = _module(cfg, sd, device)
     inst = FakeInstances(sizes, pred_boxes=FakeBoxes(g["boxes"][0].to(device)))
     with torch.no_grad():
@@ -30,7 +30,7 @@ def test_refinenet_single_test_box(device):
 
 
 def test_refinenet_single_test_octagon(device):
-    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("single_octagon_v128")
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("smooth_single_octagon_v128")
     cfg.initial = "octagon"
     net = _module(cfg, sd, device)
     ext = ExtremePoints(g["ext_points"][0].clone().to(device))
@@ -48,15 +48,15 @@ def test_refinenet_single_test_octagon(device):
 
 
 def test_refinenet_batched(device):
-    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("batched_box_v128")
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("smooth_batched_box_v196")
     cfg.vis_path = True
     net = _module(cfg, sd, device)
-    insts = [FakeInstances(sizes[i], pred_boxes=FakeBoxes(g["boxes"][i].to(device))) for i in range(2)]
+    insts = [FakeInstances(sizes[i], pred_boxes=FakeBoxes(g["boxes"][i].to(device))) for i in range(3)]
     with torch.no_grad():
         res, _ = net(feats.to(device), insts, None)
     got = torch.cat([r.pred_polys.tensor for r in res])
     assert coord_rel_err(got, g["pred2"]) < REL_TOL
-    assert res[0].pred_path.shape == (3, 4, 128, 2)
+    assert res[0].pred_path.shape == (3, 4, 196, 2)
 
 
 def test_bottom_out_channels_last_feeds_the_gather(device):
@@ -70,7 +70,7 @@ def test_bottom_out_channels_last_feeds_the_gather(device):
     assert "bottom_out.0.norm.weight" in sd and "bottom_out.1.weight" in sd and "bottom_out.0.bias" not in sd
     net.load_state_dict(sd)
     net = net.to(device).eval()
-    feats = synthetic.make_features(1, 256, 24, 32, 5).to(device)
+    feats = synthetic.make_smooth_features(1, 256, 24, 32, 5).to(device)
     boxes = synthetic.make_boxes(4, 96, 128, 6, r_min=6, r_max=30)
     inst = FakeInstances((96, 128), pred_boxes=FakeBoxes(boxes.clone().to(device)))
     with torch.no_grad():

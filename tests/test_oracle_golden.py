@@ -73,7 +73,8 @@ def test_snake_net_restatement():
         assert rel_err(state.pow(2).sum(dim=2).sqrt(), g[tag + "_state_l2"]) < 1e-5
 
 
-DANCE_CASES = ("single_box_v196", "batched_box_v128", "single_octagon_v128", "plain_demean_v128")
+DANCE_CASES = ("single_box_v196", "batched_box_v128", "single_octagon_v128", "plain_demean_v128",
+               "smooth_single_box_v128", "smooth_single_octagon_v128", "smooth_batched_box_v196")
 
 
 def dance_case_inputs(tag):
@@ -83,7 +84,8 @@ def dance_case_inputs(tag):
     cfg, sd, ck = dance_state_dict(int(g["weight_seed"]), int(g["num_sampling"]), **over)
     assert abs(ck - float(g["checksum"])) < 1e-6 * ck, "weights differ from the fixture's"
     hf, wf, batch = int(g["hf"]), int(g["wf"]), int(g["batch"])
-    feats = synthetic.make_features(batch, 256, hf, wf, int(g["feat_seed"]), attention=att)
+    make = synthetic.make_smooth_features if int(g["smooth"]) else synthetic.make_features
+    feats = make(batch, 256, hf, wf, int(g["feat_seed"]), attention=att)
     image_idx = g["image_idx"] if g["image_idx"].numel() else None
     sizes = (hf * 4, wf * 4) if image_idx is None else [(hf * 4, wf * 4)] * batch
     return g, cfg, sd, feats, image_idx, sizes
@@ -103,7 +105,7 @@ def test_dsnake_restatement():
     g = golden("g6_dsnake")
     cfg, sd, ck = dsnake_state_dict(int(g["weight_seed"]))
     assert abs(ck - float(g["checksum"])) < 1e-6 * ck
-    feats = synthetic.make_features(2, 256, int(g["hf"]), int(g["wf"]), int(g["feat_seed"]), attention=False)
+    feats = synthetic.make_smooth_features(2, 256, int(g["hf"]), int(g["wf"]), int(g["feat_seed"]), attention=False)
     out = snake_ref.dsnake_deform(sd, feats, [g["boxes"][0], g["boxes"][1]])
     assert torch.equal(out["init"], g["init"])
     assert rel_err(out["exts"], g["exts"]) < 1e-5
