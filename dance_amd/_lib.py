@@ -33,6 +33,24 @@ class SnakeNetStruct(ctypes.Structure):
     ]
 
 
+class SnakeNet16Struct(ctypes.Structure):
+    """Mirror of `dance_snake_net16` (include/dance_hip.h)."""
+
+    _fields_ = [
+        ("head_w", c_void_p), ("head_bs", c_void_p), ("head_scale", c_void_p), ("head_shift", c_void_p),
+        ("res_w", c_void_p * 7), ("res_bs", c_void_p * 7), ("res_scale", c_void_p * 7),
+        ("res_shift", c_void_p * 7),
+        ("fuse_w", c_void_p), ("fuse_bs", c_void_p), ("pred0_wg", c_void_p), ("pred0_b", c_void_p),
+        ("fuse_w_split", c_void_p), ("pred0_w_split", c_void_p),
+        ("pred1_w", c_void_p), ("pred1_bs", c_void_p),
+        ("pred2_w", c_void_p), ("pred2_b", c_void_p),
+        ("head_winv", c_float), ("res_winv", c_float * 7), ("fuse_winv", c_float),
+        ("pred1_winv", c_float),
+        ("dilation", c_int * 7),
+        ("feat_channels", c_int),
+    ]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every symbol include/dance_hip.h declares
 SIGNATURES = {
@@ -58,6 +76,15 @@ SIGNATURES = {
     "dance_snake_evolve": (c_int, [POINTER(SnakeNetStruct), P, P, P, P, P, P, P, P, c_int64, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_float, c_float, c_int, POINTER(c_void_p), P]),
+    "dance_conv16": (c_int, [P, c_int64, c_int64, P, P, c_float, P, P, P, c_int, c_int, c_int, P,
+                             c_int64, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_fuse16": (c_int, [P, c_int64, c_int64, P, P, c_float, P, P, P, c_int64, c_int64, c_int,
+                             c_int, P]),
+    "dance_gather_head16": (c_int, [P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_snake_evolve16": (c_int, [POINTER(SnakeNet16Struct), POINTER(SnakeNetStruct), P, P, P, P, P,
+                                     P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_float, c_float, POINTER(c_void_p), P]),
 }
 
 _lib = None

@@ -24,8 +24,9 @@ SOURCES = [
     ("exact_ops.hip", ["-ffp-contract=off"]),
     ("gather.hip", []),
     ("snake_mfma.hip", []),
+    ("snake16.hip", []),
 ]
-HEADERS = ["common.h", "sampling.h", os.path.join("..", "..", "include", "dance_hip.h")]
+HEADERS = ["common.h", "sampling.h", "p16.h", os.path.join("..", "..", "include", "dance_hip.h")]
 
 
 def _newer(target, deps):

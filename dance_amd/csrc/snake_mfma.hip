@@ -20,11 +20,11 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "p16.h"
 #include "sampling.h"
 
 using dance::launch_check;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -127,35 +127,58 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[RT], const ConvArgs &a, l
     const int v = a.v;
     const bool relu = a.flags & DANCE_EP_RELU, affine = a.flags & DANCE_EP_AFFINE;
     const bool resid = a.flags & DANCE_EP_RESIDUAL, maxv = a.flags & DANCE_EP_MAXV;
+    const bool p16 = a.flags & DANCE_EP_OUT_P16;
+    // register group g holds channels o0 + 8g + 4*hi + (0..3) for the lane's vertex column
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float sc = affine ? a.scale[o] : 1.0f;
-        const float sh = affine ? a.shift[o] : 0.0f;
-        float m = -INFINITY;
+    for (int g = 0; g < 4; ++g) {
+        float sc[4], sh[4], m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = o0 + 8 * g + 4 * hi + i;
+            sc[i] = affine ? a.scale[o] : 1.0f;
+            sh[i] = affine ? a.shift[o] : 0.0f;
+            m[i] = -INFINITY;
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int vv = rt * 32 + lo;
-            float val = acc[rt][r];
-            if (relu)
-                val = val > 0.0f ? val : (val != val ? val : 0.0f);
-            if (affine)
-                val = val * sc + sh;
-            if (vv < v) {
+            if (vv >= v)
+                continue;
+            float val[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = o0 + 8 * g + 4 * hi + i;
+                float x = acc[rt][4 * g + i];
+                if (relu)
+                    x = x > 0.0f ? x : (x != x ? x : 0.0f);
+                if (affine)
+                    x = x * sc[i] + sh[i];
                 if (resid)
-                    val += a.residual[nn * a.y_stride + (long long)o * v + vv];
-                if (maxv)
-                    m = dance::nan_max(val, m);
-                else
-                    a.y[nn * a.y_stride + (long long)o * v + vv] = val;
+                    x += a.residual[nn * a.y_stride + (long long)o * v + vv];
+                val[i] = x;
+                m[i] = dance::nan_max(x, m[i]);
+            }
+            if (p16) {
+                // y is a P16 block (p16.h): contour stride y_stride halfs, 128-channel slots
+                _Float16 *slot = reinterpret_cast<_Float16 *>(a.y) + nn * a.y_stride +
+                                 (long long)(o0 >> 7) * 256 * v;
+                dance::store_p16(slot, v, ((o0 & 127) >> 3) + g, vv, hi, val);
+            } else if (!maxv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a.y[nn * a.y_stride + (long long)(o0 + 8 * g + 4 * hi + i) * v + vv] = val[i];
             }
         }
         if (maxv) {
 #pragma unroll
-            for (int s = 16; s >= 1; s >>= 1)
-                m = dance::nan_max(__shfl_xor(m, s, 64), m);
-            if (lo == 0)
-                a.y[nn * a.cout + o] = m;
+            for (int i = 0; i < 4; ++i) {
+                float mm = m[i];
+#pragma unroll
+                for (int s = 16; s >= 1; s >>= 1)
+                    mm = dance::nan_max(__shfl_xor(mm, s, 64), mm);
+                if (lo == 0)
+                    a.y[nn * a.cout + o0 + 8 * g + 4 * hi + i] = mm;
+            }
         }
     }
 }
@@ -396,7 +419,8 @@ extern "C" int dance_circconv(const float *x, int64_t x_stride, const float *w_p
     DANCE_REQUIRE((flags & DANCE_EP_ROWINIT) ? rowinit != nullptr : bias != nullptr);
     DANCE_REQUIRE(!(flags & DANCE_EP_AFFINE) || (scale && shift));
     DANCE_REQUIRE(!(flags & DANCE_EP_RESIDUAL) || residual);
-    DANCE_REQUIRE((flags & DANCE_EP_MAXV) || y_stride >= (int64_t)cout * v);
+    DANCE_REQUIRE((flags & (DANCE_EP_MAXV | DANCE_EP_OUT_P16)) || y_stride >= (int64_t)cout * v);
+    DANCE_REQUIRE(!(flags & DANCE_EP_OUT_P16) || !(flags & (DANCE_EP_MAXV | DANCE_EP_RESIDUAL)));
     ConvArgs a;
     a.x = x; a.x_stride = x_stride; a.w = w_packed; a.bias = bias; a.scale = scale;
     a.shift = shift; a.residual = residual; a.rowinit = rowinit; a.y = y; a.y_stride = y_stride;
@@ -595,6 +619,95 @@ extern "C" int dance_snake_evolve(const dance_snake_net *net, const float *feat,
     DANCE_TRY(mark());
     DANCE_TRY(dance_circconv(w.p1, 256ll * v, net->pred1_w, net->pred1_b, nullptr, nullptr, nullptr,
                              nullptr, w.p2, 64ll * v, n, v, 256, 64, 1, 1, DANCE_EP_RELU, stream));
+    DANCE_TRY(mark());
+    DANCE_TRY(dance_offset_update(w.p2, 64ll * v, net->pred2_w, net->pred2_b, loc,
+                                  individual_scale ? whs : nullptr, use_att ? w.att_s : nullptr, out,
+                                  n, v, 64, clip_first, clip_x_max, clip_y_max, stream));
+    DANCE_TRY(mark());
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------
+// One evolve step in the fast precision mode (P16 activations, 3 x f16 MFMA): same stages,
+// fusion + row constant + prediction[0] fused into one kernel that reads the state once.
+// ------------------------------------------------------------------------------------
+extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_snake_net *net32,
+                                    const float *feat, const float *att, const float *loc,
+                                    const int32_t *image_idx, const float *whs, const float *x_in,
+                                    float *out, void *workspace, int64_t workspace_bytes, int n, int v,
+                                    int b, int hf, int wf, int padding_mode, int deloc_type,
+                                    int individual_scale, int use_att, int clip_first,
+                                    float clip_x_max, float clip_y_max, void **stage_events_host,
+                                    void *stream)
+{
+    DANCE_REQUIRE(net != nullptr && n >= 0);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr);
+    DANCE_REQUIRE(v >= 16 && v <= 256 && v % 4 == 0);
+    const int c = net->feat_channels;
+    DANCE_REQUIRE(c >= 64 && c % 64 == 0 && c + 2 <= 272);
+    DANCE_REQUIRE(!individual_scale || whs != nullptr);
+    DANCE_REQUIRE(!use_att || att != nullptr);
+    DANCE_REQUIRE(x_in != nullptr ? net32 != nullptr : feat != nullptr);
+    Workspace w = carve(workspace, n, v, 272);
+    DANCE_REQUIRE(workspace_bytes >= w.bytes);
+    _Float16 *state = reinterpret_cast<_Float16 *>(w.state);     // (n, 8 slots) P16
+    _Float16 *p1 = reinterpret_cast<_Float16 *>(w.p1);           // (n, 2 slots) P16
+    const long long slot = 256ll * v, sstride = 8 * slot, pstride = 2 * slot;
+    int stage = 0;
+    auto mark = [&]() -> int {
+        if (stage_events_host == nullptr)
+            return 0;
+        hipError_t e = hipEventRecord((hipEvent_t)stage_events_host[stage++], (hipStream_t)stream);
+        return e == hipSuccess ? 0 : dance::fail((int)e, "dance_snake_evolve16", hipGetErrorString(e));
+    };
+    DANCE_TRY(mark());
+    if (x_in != nullptr) {
+        // precomputed fp32 input (Dsnake init): exact-fp32 head block writing P16
+        DANCE_TRY(dance_circconv(x_in, (long long)(c + 2) * v, net32->head_w, net32->head_b,
+                                 net32->head_scale, net32->head_shift, nullptr, nullptr,
+                                 reinterpret_cast<float *>(state), sstride, n, v, c + 2, 128, 9, 1,
+                                 DANCE_EP_RELU | DANCE_EP_AFFINE | DANCE_EP_OUT_P16, stream));
+    } else {
+        DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
+                                      net->head_winv, net->head_scale, net->head_shift, state, sstride,
+                                      use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
+                                      deloc_type, stream));
+    }
+    DANCE_TRY(mark());
+    for (int i = 0; i < 7; ++i) {
+        DANCE_TRY(dance_conv16(state + i * slot, sstride, slot, net->res_w[i], net->res_bs[i],
+                               net->res_winv[i], net->res_scale[i], net->res_shift[i], nullptr, 1, 1, 0,
+                               state + (i + 1) * slot, sstride, slot, nullptr, 0, n, v, 128, 128, 9,
+                               net->dilation[i], stream));
+        DANCE_TRY(mark());
+    }
+    if (v <= 128) {
+        DANCE_TRY(dance_fuse16(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv,
+                               net->pred0_wg, net->pred0_b, p1, pstride, slot, n, v, stream));
+        DANCE_TRY(mark());
+        DANCE_TRY(mark());      // row constant: inside the fused kernel
+        DANCE_TRY(mark());      // prediction[0]: inside the fused kernel
+    } else {
+        // larger rings: the 512-output tile does not fit the register file; same weights
+        // (outputs 0..255 = fusion, 256..511 = prediction[0]) through three launches
+        DANCE_REQUIRE(net->fuse_w_split != nullptr && net->pred0_w_split != nullptr);
+        DANCE_TRY(dance_conv16(state, sstride, slot, net->fuse_w_split, net->fuse_bs, net->fuse_winv,
+                               nullptr, nullptr, nullptr, 0, 0, 1, nullptr, 0, 0, w.gmax, 0, n, v,
+                               1024, 256, 1, 1, stream));
+        DANCE_TRY(mark());
+        DANCE_TRY(dance_row_constant(w.gmax, net->pred0_wg, net->pred0_b, w.h, n, 256, 256, stream));
+        DANCE_TRY(mark());
+        DANCE_TRY(dance_conv16(state, sstride, slot, net->pred0_w_split, nullptr, net->fuse_winv,
+                               nullptr, nullptr, w.h, 0, 1, 0, p1, pstride, slot, nullptr, 0, n, v,
+                               1024, 256, 1, 1, stream));
+        DANCE_TRY(mark());
+    }
+    DANCE_TRY(dance_conv16(p1, pstride, slot, net->pred1_w, net->pred1_bs, net->pred1_winv, nullptr,
+                           nullptr, nullptr, 0, 1, 0, nullptr, 0, 0, w.p2, 64ll * v, n, v, 256, 64, 1,
+                           1, stream));
     DANCE_TRY(mark());
     DANCE_TRY(dance_offset_update(w.p2, 64ll * v, net->pred2_w, net->pred2_b, loc,
                                   individual_scale ? whs : nullptr, use_att ? w.att_s : nullptr, out,

@@ -4,6 +4,8 @@ allocation and stream plumbing only -- all arithmetic happens in libdance_hip.so
 Every function requires CUDA(HIP) tensors and raises RuntimeError otherwise; there is no
 CPU or torch fallback.
 """
+import math
+
 import torch
 
 from ._lib import check, current_stream, lib, ptr
@@ -108,6 +110,69 @@ def pack_conv_weight(weight):
     w = torch.zeros((k, cin_pad, cout), dtype=torch.float32, device=weight.device)
     w[:, :cin, :] = weight.float().permute(2, 1, 0)
     return w.contiguous()
+
+
+def pack_conv_weight16(weight):
+    """Conv1d weight (Cout, Cin, K) -> split-half packing for the fast precision mode:
+    (2, K, Cin_pad16/8, Cout, 8) fp16 = hi/lo planes of w * 2^s, plus 2^s.  The power-of-two
+    scale keeps the lo halves normal fp16 numbers and is undone exactly in the epilogue."""
+    cout, cin, k = weight.shape
+    cin_pad = (cin + 15) // 16 * 16
+    w = torch.zeros((cout, cin_pad, k), dtype=torch.float32, device=weight.device)
+    w[:, :cin, :] = weight.float()
+    amax = float(w.abs().max())
+    s = 2.0 ** math.floor(math.log2(1024.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+    ws = w * s
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+
+    def arrange(t):                    # (Cout, Cin_pad, K) -> (K, Cin_pad/8, Cout, 8)
+        return t.permute(2, 1, 0).reshape(k, cin_pad // 8, 8, cout).permute(0, 1, 3, 2)
+
+    return torch.stack([arrange(hi), arrange(lo)]).contiguous(), s
+
+
+def to_p16(x):
+    """(N, C, V) fp32 channel-major -> P16 block (N, C/128 slots, 2, 16, V, 8) fp16
+    (C a multiple of 128).  Test / glue helper; the kernels produce P16 themselves."""
+    n, c, v = x.shape
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    t = torch.stack([hi, lo], dim=1).reshape(n, 2, c // 128, 16, 8, v)      # n, plane, slot, cb, j, v
+    return t.permute(0, 2, 1, 3, 5, 4).contiguous()
+
+
+def from_p16(p):
+    """Inverse of to_p16: (N, slots, 2, 16, V, 8) fp16 -> (N, C, V) fp32 (hi + lo)."""
+    n, slots, _, _, v, _ = p.shape
+    f = p.float()
+    x = f[:, :, 0] + f[:, :, 1]                                              # n, slot, cb, v, j
+    return x.permute(0, 1, 2, 4, 3).reshape(n, slots * 128, v).contiguous()
+
+
+def conv16(x16, w16, scale_pow2, bias, *, cin, cout, v, dilation=1, bn_scale=None, bn_shift=None,
+           residual=False, relu=False, rowinit=None, maxv=False, out_f32=False):
+    """dance_conv16 on a P16 block (N, slots, 2, 16, V, 8); returns P16 (N, cout/128 slots, ...)
+    or fp32 (N, cout, V) / (N, cout) with out_f32 / maxv."""
+    _need_gpu(x16, w16)
+    n = x16.size(0)
+    taps = w16.size(1)
+    slot = 256 * v
+    bias_s = None if bias is None else (bias.float() * scale_pow2).contiguous()
+    if maxv:
+        y16, yf, yfs = None, torch.empty((n, cout), dtype=torch.float32, device=x16.device), 0
+    elif out_f32:
+        y16, yf, yfs = None, torch.empty((n, cout, v), dtype=torch.float32, device=x16.device), cout * v
+    else:
+        slots = max(1, cout // 128)
+        y16 = torch.zeros((n, slots, 2, 16, v, 8), dtype=torch.float16, device=x16.device)
+        yf, yfs = None, 0
+    with torch.cuda.device(x16.device):
+        check(lib().dance_conv16(ptr(x16), x16.stride(0), slot, ptr(w16), ptr(bias_s), 1.0 / scale_pow2,
+                                 ptr(bn_scale), ptr(bn_shift), ptr(rowinit), int(residual), int(relu),
+                                 int(maxv), ptr(y16), 0 if y16 is None else y16.stride(0), slot, ptr(yf),
+                                 yfs, n, v, cin, cout, taps, dilation, current_stream()), "conv16")
+    return yf if y16 is None else y16
 
 
 def circconv(x, w_packed, bias, *, cin, dilation=1, scale=None, shift=None, residual=None,

@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import ops
-from ._lib import EVOLVE_EVENTS, SnakeNetStruct, check, current_stream, lib, ptr
+from ._lib import EVOLVE_EVENTS, SnakeNet16Struct, SnakeNetStruct, check, current_stream, lib, ptr
 
 BN_EPS = 1e-5                          # nn.BatchNorm1d default, snake_head.py:146
 DEFAULT_DILATIONS = (1, 1, 1, 2, 2, 4, 4)   # defaults.py:60-64 / dsnake_head.py:102
@@ -81,6 +81,49 @@ class SnakeNetWeights:
             s.dilation[i] = self.dilations[i]
         s.feat_channels = self.feature_dim - 2
         self.struct = s
+        self._pack16(sdd)
+
+    def _pack16(self, sdd):
+        """Split-half (P16) packing for the fast precision mode (dance_snake_evolve16)."""
+        t = self.tensors
+        s = SnakeNet16Struct()
+        scales = {}
+
+        def pack(name, weight, bias):
+            w16, sc = ops.pack_conv_weight16(weight)
+            t[name + "_w16"] = w16
+            scales[name] = sc
+            if bias is not None:
+                t[name + "_bs"] = (bias * sc).contiguous()
+            return w16.data_ptr(), 1.0 / sc
+
+        s.head_w, s.head_winv = pack("head", sdd["head.conv.fc.weight"], sdd["head.conv.fc.bias"])
+        s.head_bs = t["head_bs"].data_ptr()
+        s.head_scale, s.head_shift = t["head_scale"].data_ptr(), t["head_shift"].data_ptr()
+        for i in range(7):
+            n = "res%d" % i
+            s.res_w[i], s.res_winv[i] = pack(n, sdd[n + ".conv.fc.weight"], sdd[n + ".conv.fc.bias"])
+            s.res_bs[i] = t[n + "_bs"].data_ptr()
+            s.res_scale[i], s.res_shift[i] = t[n + "_scale"].data_ptr(), t[n + "_shift"].data_ptr()
+            s.dilation[i] = self.dilations[i]
+        # fusion and the state columns of prediction[0] as ONE 512-output GEMM (common scale)
+        p0 = sdd["prediction.0.weight"]
+        both = torch.cat([sdd["fusion.weight"], p0[:, 256:, :]], dim=0)          # (512, 1024, 1)
+        fb = torch.cat([sdd["fusion.bias"], torch.zeros_like(sdd["fusion.bias"])])
+        s.fuse_w, s.fuse_winv = pack("fuse", both, fb)
+        s.fuse_bs = t["fuse_bs"].data_ptr()
+        w16 = t["fuse_w16"]                                                       # (2,1,128,512,8)
+        t["fuse_split_w16"] = w16[:, :, :, :256].contiguous()
+        t["pred0_split_w16"] = w16[:, :, :, 256:].contiguous()
+        s.fuse_w_split = t["fuse_split_w16"].data_ptr()
+        s.pred0_w_split = t["pred0_split_w16"].data_ptr()
+        s.pred0_wg, s.pred0_b = t["pred0_wg"].data_ptr(), t["pred0_b"].data_ptr()
+        s.pred1_w, s.pred1_winv = pack("pred1", sdd["prediction.2.weight"], sdd["prediction.2.bias"])
+        s.pred1_bs = t["pred1_bs"].data_ptr()
+        s.pred2_w, s.pred2_b = t["pred2_w"].data_ptr(), t["pred2_b"].data_ptr()
+        s.feat_channels = self.feature_dim - 2
+        self.struct16 = s
+        self.scales16 = scales
 
 
 def sub_state_dict(sd, prefix):
@@ -102,7 +145,12 @@ class ContourDeformer:
     MAX_CHUNK = 4096      # contours per kernel sequence: bounds the workspace
 
     def __init__(self, nets, padding="reflection", de_loc_type="derange", individual_scale=True,
-                 attention=True, fused_head=True):
+                 attention=True, fused_head=True, precision="fp16x3"):
+        """precision: "fp16x3" -- split-half operands, three f16 MFMAs per product, fp32
+        accumulation (fp32-level accuracy, the default); "fp32" -- exact fp32 MFMA."""
+        if precision not in ("fp16x3", "fp32"):
+            raise ValueError("precision must be 'fp16x3' or 'fp32'")
+        self.precision = precision
         self.nets = list(nets)
         self.padding = ops.PAD_REFLECTION if padding == "reflection" else ops.PAD_ZEROS
         self.deloc = ops.DELOC[de_loc_type]
@@ -154,14 +202,20 @@ class ContourDeformer:
             stream = current_stream()
             for n0 in range(0, n, chunk):
                 nb = min(chunk, n - n0)
-                check(lib().dance_snake_evolve(
-                    ctypes.byref(net.struct), ptr(feat), ptr(att), ptr(locations[n0:]),
+                args16 = ()
+                fn = lib().dance_snake_evolve
+                fast = self.precision == "fp16x3" and c % 64 == 0
+                if fast:
+                    fn = lib().dance_snake_evolve16
+                    args16 = (ctypes.byref(net.struct16),)
+                check(fn(
+                    *args16, ctypes.byref(net.struct), ptr(feat), ptr(att), ptr(locations[n0:]),
                     ptr(image_idx[n0:]) if image_idx is not None else None,
                     ptr(whs[n0:]) if whs is not None else None,
                     ptr(x_in[n0:]) if x_in is not None else None, ptr(out[n0:]), ptr(ws), need,
                     nb, v, b, hf, wf, self.padding, self.deloc, int(self.individual_scale),
                     int(use_att), int(clip_first and n0 == 0), float(clip_max[0]), float(clip_max[1]),
-                    int(self.fused_head), ev, stream), "snake_evolve")
+                    *(() if fast else (int(self.fused_head),)), ev, stream), "snake_evolve")
         return out
 
     def deform(self, features, init_contours, image_idx, image_sizes, whs, layout="nchw",

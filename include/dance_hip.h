@@ -100,7 +100,8 @@ enum {
     DANCE_EP_AFFINE = 2,    /* y = y*scale[o] + shift[o]  (eval BatchNorm1d after ReLU) */
     DANCE_EP_RESIDUAL = 4,  /* y += residual[n][o][v]                                   */
     DANCE_EP_ROWINIT = 8,   /* accumulator starts at rowinit[n][o] instead of bias[o]   */
-    DANCE_EP_MAXV = 16      /* store max over v into y (n,cout) instead of (n,cout,v)   */
+    DANCE_EP_MAXV = 16,     /* store max over v into y (n,cout) instead of (n,cout,v)   */
+    DANCE_EP_OUT_P16 = 32   /* y is a split-half (P16) block, y_stride in halfs         */
 };
 /* Circular dilated Conv1d over the vertex ring as an fp32 MFMA implicit GEMM:
  *   y[n][o][v] = ep( bias[o] + sum_{t<taps} sum_{c<cin} w[t][c][o] * x[n][c][(v+(t-taps/2)*dilation) mod V] )
@@ -181,6 +182,72 @@ int dance_snake_evolve(const dance_snake_net *net_host, const float *feat, const
                        int padding_mode, int deloc_type, int individual_scale, int use_att,
                        int clip_first, float clip_x_max, float clip_y_max, int fused_head,
                        void **stage_events_host, void *stream);
+
+/* ------------------------------------------------ fast precision mode (P16) ------- *
+ * Activations and weights as fp16 hi/lo pairs (22 significant bits), every product as three
+ * f16 MFMAs accumulated in fp32: fp32-level accuracy at 16/3 of the fp32-MFMA rate
+ * (dance_amd/csrc/p16.h has the format).  Values beyond the fp16 range (|x| >= 65504) turn
+ * into NaN -- loud, never silently wrong; dance_snake_evolve stays the exact-fp32 path.
+ *
+ * P16 block of C channels (C % 128 == 0 or C <= 128; always slots of 128):
+ *   [slot][plane hi/lo][c/8][v][8] halfs, slot stride given by the caller.
+ * Packed weights w16: [plane][tap][cin_pad16/8][cout][8] halfs of (w * 2^s), with
+ * bias_scaled = bias * 2^s and w_inv_scale = 2^-s (dance_amd.ops.pack_conv_weight16).       */
+
+/* Same op as dance_circconv on P16 input.  Output either P16 (y16) or fp32 channel-major
+ * (y_f32); residual != 0 adds the input itself (needs cin == cout <= 128); rowinit (n,cout)
+ * replaces the bias as accumulator start; maxv != 0 writes max over the ring to y_f32 (n,cout).
+ * reference: SnakeBlock snake_head.py:140-153 + residual :266; k=1 Conv1d :252-258. */
+int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
+                 const float *bias_scaled, float w_inv_scale, const float *scale,
+                 const float *shift, const float *rowinit, int residual, int relu, int maxv,
+                 void *y16, int64_t y_stride, int64_t y_slot_stride, float *y_f32,
+                 int64_t yf_stride, int n, int v, int cin, int cout, int taps, int dilation,
+                 void *stream);
+
+/* fusion Conv1d + max over the ring + row constant + prediction[0] in one pass over the
+ * (n, 1024, v) P16 state.  w16 packs fusion.weight (outputs 0..255) and the 1024 state
+ * columns of prediction[0] (outputs 256..511) as one 512-output GEMM; bias_scaled (512) =
+ * fusion bias * 2^s then zeros; wg (256,256) [g][o] fp32 = prediction[0]'s global-state
+ * columns; pred_bias (256).  Output: relu(prediction[0]) as a 2-slot P16 block.  v <= 128
+ * (larger rings run the same stages as three dance_conv16 / dance_row_constant launches).
+ * reference: _SnakeNet.forward snake_head.py:269-282. */
+int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
+                 const float *bias_scaled, float w_inv_scale, const float *wg,
+                 const float *pred_bias, void *y16, int64_t y_stride, int64_t y_slot_stride, int n,
+                 int v, void *stream);
+
+/* Fused gather + de_location + head SnakeBlock writing slot 0 of a P16 block
+ * (as dance_gather_circconv_head; c % 64 == 0). */
+int dance_gather_head16(const float *feat, const float *att, const float *loc,
+                        const int32_t *image_idx, const void *w16, const float *bias_scaled,
+                        float w_inv_scale, const float *scale, const float *shift, void *y16,
+                        int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf, int c,
+                        int padding_mode, int deloc_type, void *stream);
+
+typedef struct dance_snake_net16 {
+    const void *head_w;  const float *head_bs, *head_scale, *head_shift;
+    const void *res_w[7]; const float *res_bs[7], *res_scale[7], *res_shift[7];
+    const void *fuse_w;  const float *fuse_bs, *pred0_wg, *pred0_b;   /* fuse_w: (2,1,128,512,8) */
+    const void *fuse_w_split, *pred0_w_split;     /* the two 256-output halves of fuse_w, packed
+                                                     separately (2,1,128,256,8): rings > 128 */
+    const void *pred1_w; const float *pred1_bs;
+    const float *pred2_w, *pred2_b;
+    float head_winv, res_winv[7], fuse_winv, pred1_winv;
+    int dilation[7];
+    int feat_channels;
+} dance_snake_net16;
+
+/* dance_snake_evolve in the fast precision mode (same workspace size, same stage events;
+ * the fusion / row-constant / prediction[0] stages are one kernel).  net32 is only needed
+ * with x_in (fp32 precomputed head input). */
+int dance_snake_evolve16(const dance_snake_net16 *net_host, const dance_snake_net *net32_host,
+                         const float *feat, const float *att, const float *loc,
+                         const int32_t *image_idx, const float *whs, const float *x_in, float *out,
+                         void *workspace, int64_t workspace_bytes, int n, int v, int b, int hf,
+                         int wf, int padding_mode, int deloc_type, int individual_scale, int use_att,
+                         int clip_first, float clip_x_max, float clip_y_max,
+                         void **stage_events_host, void *stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,40 @@ def test_snake_block_shapes_vs_oracle(device, v, d):
     assert rel_err(got, want, floor=float(want.abs().max())) < 1e-5
 
 
+@pytest.mark.parametrize("v", [16, 36, 40, 128, 132, 196, 256])
+@pytest.mark.parametrize("d", [1, 2, 4])
+def test_conv16_block_vs_oracle(device, v, d):
+    """fast precision mode: residual SnakeBlock on split-half operands vs the fp32 oracle."""
+    blk = modules.SnakeBlock(128, 128)
+    sd = {k: v_.clone() for k, v_ in blk.state_dict().items()}
+    synthetic.fill_state_dict_(sd, 177 + v + d)
+    x = torch.randn((3, 128, v), generator=torch.Generator().manual_seed(v)) * 3
+    want = snake_ref.snake_block(x, sd, "", d) + x
+    w16, sc = ops.pack_conv_weight16(sd["conv.fc.weight"].to(device))
+    scale, shift = snake._fold_bn({k: t.to(device) for k, t in sd.items()}, "norm.")
+    x16 = ops.to_p16(x.to(device))
+    y16 = ops.conv16(x16, w16, sc, sd["conv.fc.bias"].to(device), cin=128, cout=128, v=v, dilation=d,
+                     bn_scale=scale, bn_shift=shift, residual=True, relu=True)
+    got = ops.from_p16(y16)
+    assert rel_err(got, want, floor=float(want.abs().max())) < 1e-5
+    # fp32 output + max over the ring
+    yf = ops.conv16(x16, w16, sc, sd["conv.fc.bias"].to(device), cin=128, cout=128, v=v, dilation=d,
+                    relu=True, out_f32=True)
+    raw = torch.relu(snake_ref.circ_conv(x, sd["conv.fc.weight"], sd["conv.fc.bias"], d))
+    assert rel_err(yf, raw, floor=float(raw.abs().max())) < 1e-5
+    m = ops.conv16(x16, w16, sc, sd["conv.fc.bias"].to(device), cin=128, cout=128, v=v, dilation=d,
+                   relu=True, maxv=True)
+    assert rel_err(m, raw.max(dim=2)[0], floor=float(raw.abs().max())) < 1e-5
+
+
+def test_p16_overflow_is_loud(device):
+    """values beyond the fp16 range become NaN in the fast mode, never silently wrong"""
+    x = torch.zeros((1, 128, 32))
+    x[0, 3, 5] = 1.0e5
+    y = ops.from_p16(ops.to_p16(x.to(device)))
+    assert torch.isnan(y[0, 3, 5]) and float(y.nan_to_num().abs().max()) == 0.0
+
+
 def test_pointwise_rowinit_maxv(device):
     g = torch.Generator().manual_seed(5)
     n, v = 5, 128
@@ -76,11 +110,11 @@ def test_pointwise_rowinit_maxv(device):
     assert float(out[:, 64:].abs().max()) == 0.0
 
 
-def _net_forward(sd, x, device, whs=None):
+def _net_forward(sd, x, device, precision="fp16x3"):
     """whole _SnakeNet through dance_snake_evolve's x_in path: returns raw offsets (N,V,2)."""
     net = snake.SnakeNetWeights(sd, device)
     d = snake.ContourDeformer([net], padding="zeros", de_loc_type="demin", individual_scale=False,
-                              attention=False)
+                              attention=False, precision=precision)
     n, _, v = x.shape
     loc = torch.zeros((n, v, 2), device=device)
     feat = torch.zeros((1, 2, 2, 256), device=device)
@@ -88,25 +122,26 @@ def _net_forward(sd, x, device, whs=None):
                     x_in=x.to(device).contiguous())
 
 
-def test_snake_net_golden(device):
+@pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
+def test_snake_net_golden(device, precision):
     g = golden("g4_snake_net")
     for tag in ("v128", "v196", "v40"):
         net = modules._SnakeNet(128, 258, (1, 1, 1, 2, 2, 4, 4))
         sd = {k: v.clone() for k, v in net.state_dict().items()}
         synthetic.fill_state_dict_(sd, int(g[tag + "_seed"]))
-        off = _net_forward(sd, g[tag + "_x"], device)            # loc = 0 -> output = offsets
+        off = _net_forward(sd, g[tag + "_x"], device, precision)  # loc = 0 -> output = offsets
         want = g[tag + "_y"].permute(0, 2, 1)
         assert rel_err(off, want, floor=float(want.abs().max())) < 1e-4, tag
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("mode", ["fp16x3", "fp32", "fp32-unfused"])
 @pytest.mark.parametrize("tag", DANCE_CASES)
-def test_dance_chain_golden(device, tag, fused):
+def test_dance_chain_golden(device, tag, mode):
     g, cfg, sd, feats, image_idx, sizes = dance_case_inputs(tag)
     nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
     d = snake.ContourDeformer(nets, padding="reflection", de_loc_type=cfg.de_loc_type,
                               individual_scale=cfg.individual_scale, attention=cfg.attention,
-                              fused_head=fused)
+                              fused_head=mode != "fp32-unfused", precision=mode.split("-")[0])
     idx = None if image_idx is None else image_idx.to(device)
     preds = d.deform(feats.to(device), g["init"].to(device), idx, sizes, g["whs"].to(device))
     tol = CHAIN_TOL_SMOOTH if int(g["smooth"]) else CHAIN_TOL_WHITE
@@ -121,8 +156,9 @@ def test_dance_chain_golden(device, tag, fused):
         assert coord_rel_err(one, g["pred%d" % i]) < REL_TOL, (tag, i)
 
 
+@pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
 @pytest.mark.parametrize("tag", ["single_box_v196", "batched_box_v128", "plain_demean_v128"])
-def test_as_close_to_fp64_as_the_reference(device, tag):
+def test_as_close_to_fp64_as_the_reference(device, tag, precision):
     """white-noise fixtures, one iteration: the HIP result is no further from an fp64
     evaluation of the path than the reference's own fp32 result is (factor 2 + 1e-6)."""
     g, cfg, sd, feats, image_idx, sizes = dance_case_inputs(tag)
@@ -133,7 +169,8 @@ def test_as_close_to_fp64_as_the_reference(device, tag):
                                    num_iter=1)[0]
     nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer0."), device)]
     d = snake.ContourDeformer(nets, padding="reflection", de_loc_type=cfg.de_loc_type,
-                              individual_scale=cfg.individual_scale, attention=cfg.attention)
+                              individual_scale=cfg.individual_scale, attention=cfg.attention,
+                              precision=precision)
     idx = None if image_idx is None else image_idx.to(device)
     got = d.deform(feats.to(device), g["init"].to(device), idx, sizes, g["whs"].to(device))[0]
     e_gpu, e_ref = coord_rel_err(got, truth), coord_rel_err(g["pred0"], truth)
