@@ -7,7 +7,17 @@
 //   A lane (r = lane & 31, h = lane >> 5): W[o0 + r][channels 8h .. 8h+7]  = one 16-B word of
 //     the packed weights [plane][tap][c/8][o][8];
 //   B lane: X[channels 8h .. 8h+7][vertex r] = one 16-B word of the P16 LDS image
-//     [plane][c/8][v][8]  ->  ds_read_b128, consecutive lanes on consecutive words.
+//     [plane][c/8][VP][8]  ->  ds_read_b128, consecutive lanes on consecutive words.
+//
+// At f16 MFMA rates (32 cycles per 32x32x16) the vector ALU, not the matrix pipe, is what a
+// naive loop saturates: a wave64 VALU instruction costs 4 cycles, so a 12-MFMA step has room
+// for a few dozen of them per SIMD.  The inner loop (mfma16_core) is therefore built so that a
+// step issues only MFMAs, LDS reads with immediate offsets (compile-time row stride VP),
+// weight loads from a scalar base + a constant lane offset, and scalar pointer bumps; ring
+// positions advance incrementally once per tap.  Activations of the next chunk are staged
+// global -> registers one load per step, right AFTER the step's weight prefetch, so the
+// weight wait (in-order vmcnt) never waits for an activation load issued before it.
+//
 // Kernels: k_conv16 (residual SnakeBlock / k=1 Conv1d), k_fuse16 (fusion + max over the ring
 // + row constant + prediction[0], the 1024-channel state read once), k_gather_head16 (gather
 // + de_location + head block).
@@ -18,6 +28,8 @@
 using dance::launch_check;
 
 namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct Conv16Args {
     const _Float16 *x;          // P16 input
@@ -32,7 +44,7 @@ struct Conv16Args {
     float *yf;                  // fp32 channel-major output (or null)
     long long yf_stride;
     const float *rowinit;       // per-contour accumulator start (n, cout), unscaled, or null
-    int v, cin, cout, taps, dilation, ck, relu, residual, maxv;
+    int v, cin, cout, taps, dilation, relu, residual, maxv;
 };
 
 __device__ __forceinline__ int ring16(int vv, int off, int v)
@@ -44,197 +56,310 @@ __device__ __forceinline__ int ring16(int vv, int off, int v)
     return t;
 }
 
-// acc[ot][rt] += W[o-tiles, chunk] * X[chunk, :] for one LDS-resident chunk of `cbc` channel
-// blocks.  xs: LDS image [2][cbc][vp] words (16 B);  wl: this lane's weight word for tap 0,
-// block (chunk start + h), o-tile 0;  wps / wts / wbs: plane / tap / channel-block strides and
-// wos the o-tile stride of the packed weights, in words.
-template <int RT, int OTW>
-__device__ __forceinline__ void mfma16_chunk(f32x16 (&acc)[OTW][RT], const char *xs, int v, int vp,
-                                             int cbc, const h8 *__restrict__ wl, long long wps,
-                                             long long wts, long long wbs, int wos, int taps,
-                                             int dilation, int r, int h)
+// Geometry of one LDS chunk image: [plane 2][CBC channel blocks][VP words of 16 B].
+template <int RT, int CBC>
+struct Geo {
+    static constexpr int VP = RT * 32 + 1;          // odd row stride: conflict-free b128 reads
+    static constexpr int CPR = (RT + 1) / 2;        // 64-lane passes along a row
+    static constexpr int PLANE = CBC * VP * 16;     // bytes
+    static constexpr int BYTES = 2 * PLANE;
+};
+
+// acc[ot][rt] += W[o-tiles, chunk] * X[chunk, :] for one LDS-resident chunk of 2 * NST channel
+// blocks.
+//   xs + lds0   : the chunk image (Geo<RT, 2 * NST>)
+//   wchunk      : uniform byte pointer to W[plane 0][tap 0][chunk's first block][wave's o-tile 0]
+//   wlane       : this lane's constant byte offset ((h * cout + r) * 16)
+//   wps_b / wts_b / wstep_b : byte strides of a plane / a tap / two channel blocks (one step)
+//   hook(s)     : called once per step of tap 0, after the step's weight prefetch was issued
+//                 (the place for staged activation loads)
+// AD weight buffers rotate (prefetch distance AD - 1 steps); B tiles ping-pong one tile ahead.
+template <int RT, int OTW, int NST, int AD, typename Hook>
+__device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *xs, unsigned lds0, int v,
+                                            const char *wchunk, unsigned wlane, long long wps_b,
+                                            long long wts_b, long long wstep_b, int taps, int dilation,
+                                            int r, int h, Hook hook)
 {
-    const int nst = cbc >> 1;                 // steps of 16 channels
-    const int steps = taps * nst;
-    const int lds_plane = cbc * vp * 16;      // bytes
-    h8 ah_n[OTW], al_n[OTW];
+    static_assert(RT >= 2 && NST % AD == 0 && (NST * RT) % 2 == 0 && AD - 1 <= NST, "rotation parity");
+    using G = Geo<RT, 2 * NST>;
+    constexpr int SSTEP = 2 * G::VP * 16, D = AD - 1;
+    const unsigned rowb = lds0 + h * G::VP * 16;
+    const unsigned lim = rowb + v * 16, d16 = dilation * 16, v16 = v * 16;
+    unsigned p[RT];                             // LDS byte address of this lane's word, per vertex tile
 #pragma unroll
-    for (int ot = 0; ot < OTW; ++ot) {
-        ah_n[ot] = wl[ot * wos];
-        al_n[ot] = wl[wps + ot * wos];
+    for (int rt = 0; rt < RT; ++rt)
+        p[rt] = rowb + ring16(rt * 32 + r, -(taps >> 1) * dilation, v) * 16;
+
+    h8 ah[AD][OTW], al[AD][OTW];
+#define DANCE_LOAD_A(SLOT, PTR)                                                                   \
+    do {                                                                                          \
+        const char *pa_ = (PTR);                                                                  \
+        _Pragma("unroll") for (int ot_ = 0; ot_ < OTW; ++ot_) {                                   \
+            ah[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wlane + ot_ * 512);               \
+            al[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + ot_ * 512);       \
+        }                                                                                         \
+    } while (0)
+#pragma unroll
+    for (int q = 0; q < D; ++q)
+        DANCE_LOAD_A(q, wchunk + q * wstep_b);
+    h8 bh[2], bl[2];
+    bh[0] = *reinterpret_cast<const h8 *>(xs + p[0]);
+    bl[0] = *reinterpret_cast<const h8 *>(xs + p[0] + G::PLANE);
+
+    const char *wtap = wchunk;
+    for (int tap = 0; tap < taps; ++tap) {
+        const bool more = tap + 1 < taps;
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            if (s + D < NST)
+                DANCE_LOAD_A((s + D) % AD, wtap + (s + D) * wstep_b);
+            else if (more)
+                DANCE_LOAD_A((s + D) % AD, wtap + wts_b + (s + D - NST) * wstep_b);
+            if (tap == 0)
+                hook(s);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int cur = (s * RT + rt) & 1, nx = cur ^ 1;
+                // next tile: same step, next step, or step 0 of the next tap (p[0] already advanced)
+                if (rt + 1 < RT) {
+                    bh[nx] = *reinterpret_cast<const h8 *>(xs + p[rt + 1] + s * SSTEP);
+                    bl[nx] = *reinterpret_cast<const h8 *>(xs + p[rt + 1] + s * SSTEP + G::PLANE);
+                } else if (s + 1 < NST) {
+                    bh[nx] = *reinterpret_cast<const h8 *>(xs + p[0] + (s + 1) * SSTEP);
+                    bl[nx] = *reinterpret_cast<const h8 *>(xs + p[0] + (s + 1) * SSTEP + G::PLANE);
+                } else {
+                    bh[nx] = *reinterpret_cast<const h8 *>(xs + p[0]);
+                    bl[nx] = *reinterpret_cast<const h8 *>(xs + p[0] + G::PLANE);
+                }
+                // keep the prefetch ahead of this tile's MFMAs (the scheduler otherwise sinks
+                // it below them and the ping-pong collapses into load -> wait -> use)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ot = 0; ot < OTW; ++ot)
+                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % AD][ot], bh[cur], acc[ot][rt], 0, 0, 0);
+#pragma unroll
+                for (int ot = 0; ot < OTW; ++ot)
+                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bl[cur], acc[ot][rt], 0, 0, 0);
+#pragma unroll
+                for (int ot = 0; ot < OTW; ++ot)
+                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bh[cur], acc[ot][rt], 0, 0, 0);
+                if (s == NST - 1) {             // tile rt of this tap was fetched: advance to the next tap
+                    const unsigned tpos = p[rt] + d16;
+                    p[rt] = tpos >= lim ? tpos - v16 : tpos;
+                }
+            }
+        }
+        wtap += wts_b;
     }
-    int tap = 0, s = 0;
-    int idx[RT];
-    for (int step = 0; step < steps; ++step) {
-        h8 ah[OTW], al[OTW];
+#undef DANCE_LOAD_A
+}
+
+// Staging of the next chunk image: this wave's rows (wave, wave + NW, ...), lanes along the
+// row; lanes past the ring length repeat the last vertex (same value to the same address),
+// which keeps loads and stores branch-free and the staging array in registers.
+template <int RT, int CBC, int NW>
+struct StageGeo {
+    using G = Geo<RT, CBC>;
+    static constexpr int RPW = (2 * CBC) / NW;      // rows per wave
+    static constexpr int N = RPW * G::CPR;          // 16-B loads per lane
+    static_assert((2 * CBC) % NW == 0, "rows split evenly over the waves");
+};
+
+// src: uniform byte pointer to (plane 0, chunk's first block) of the P16 slot
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_load(u32x4 (&reg)[(StageGeo<RT, CBC, NW>::N)], int jlo, int jhi,
+                                           const char *src, int v, int wave, int lane)
+{
+    using S = StageGeo<RT, CBC, NW>;
 #pragma unroll
-        for (int ot = 0; ot < OTW; ++ot) {
-            ah[ot] = ah_n[ot];
-            al[ot] = al_n[ot];
+    for (int j = 0; j < S::N; ++j)
+        if (j >= jlo && j < jhi) {
+            const int row = wave + NW * (j / S::G::CPR);
+            const int plane = row >= CBC ? 1 : 0, cbl = row - plane * CBC;
+            const unsigned col = min((j % S::G::CPR) * 64 + lane, v - 1);
+            reg[j] = *reinterpret_cast<const u32x4 *>(src + (plane * 256ll + cbl * 16ll) * v + col * 16u);
         }
-        int ntap = tap, ns = s + 1;
-        if (ns == nst) {
-            ns = 0;
-            ++ntap;
-        }
-        if (step + 1 < steps) {
-            const h8 *p = wl + ntap * wts + ns * 2 * wbs;
+}
+
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_commit(const u32x4 (&reg)[(StageGeo<RT, CBC, NW>::N)], char *xs,
+                                             unsigned lds0, int v, int wave, int lane)
+{
+    using S = StageGeo<RT, CBC, NW>;
 #pragma unroll
-            for (int ot = 0; ot < OTW; ++ot) {
-                ah_n[ot] = p[ot * wos];
-                al_n[ot] = p[wps + ot * wos];
-            }
-        }
-        if (s == 0) {
-            const int off = (tap - (taps >> 1)) * dilation;
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                idx[rt] = (h * vp + ring16(rt * 32 + r, off, v)) * 16;
-        }
-        const char *xb = xs + s * 2 * vp * 16;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const h8 bh = *reinterpret_cast<const h8 *>(xb + idx[rt]);
-            const h8 bl = *reinterpret_cast<const h8 *>(xb + idx[rt] + lds_plane);
-#pragma unroll
-            for (int ot = 0; ot < OTW; ++ot) {
-                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ot], bh, acc[ot][rt], 0, 0, 0);
-                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ot], bl, acc[ot][rt], 0, 0, 0);
-                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ot], bh, acc[ot][rt], 0, 0, 0);
-            }
-        }
-        tap = ntap;
-        s = ns;
+    for (int j = 0; j < S::N; ++j) {
+        const int row = wave + NW * (j / S::G::CPR);
+        const unsigned col = min((j % S::G::CPR) * 64 + lane, v - 1);
+        *reinterpret_cast<u32x4 *>(xs + lds0 + (row * S::G::VP + col) * 16u) = reg[j];
     }
 }
 
-// copy `cbc` channel blocks (both planes) of a P16 slot into the LDS image [2][cbc][vp];
-// one row (plane, block) = v words, rows dealt to waves, lanes along the row.
-__device__ __forceinline__ void load_chunk_p16(char *xs, const _Float16 *slot, int v, int vp, int cb0,
-                                               int cbc, int wave, int nwaves, int lane)
-{
-    for (int row = wave; row < 2 * cbc; row += nwaves) {
-        const int plane = row >= cbc ? 1 : 0;
-        const int cbl = row - plane * cbc;
-        const uint4 *src = reinterpret_cast<const uint4 *>(slot + plane * 128ll * v +
-                                                            (long long)(cb0 + cbl) * v * 8);
-        uint4 *dst = reinterpret_cast<uint4 *>(xs + (long long)row * vp * 16);
-        for (int i = lane; i < v; i += 64)
-            dst[i] = src[i];
-    }
-}
-
 template <int RT, int OTW>
-__device__ __forceinline__ void init_acc16(f32x16 (&acc)[OTW][RT], const float *bias_s, int o0, int h)
+__device__ __forceinline__ void init_acc16(f32x16 (&acc)[OTW][RT], const float *bias_s, int o0, int h, float mul)
 {
 #pragma unroll
     for (int ot = 0; ot < OTW; ++ot)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float b = bias_s ? bias_s[o0 + ot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h] : 0.0f;
+        for (int g = 0; g < 4; ++g) {
+            float4 b = {0.f, 0.f, 0.f, 0.f};
+            if (bias_s)
+                b = *reinterpret_cast<const float4 *>(bias_s + o0 + ot * 32 + 8 * g + 4 * h);
+            const float bb[4] = {b.x * mul, b.y * mul, b.z * mul, b.w * mul};
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                acc[ot][rt][q] = b;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[ot][rt][4 * g + i] = bb[i];
         }
 }
 
+__device__ __forceinline__ float relu_nan(float x) { return x > 0.0f ? x : (x != x ? x : 0.0f); }
+
 // Residual SnakeBlock / k=1 Conv1d.  4 waves, one 32-channel tile each (128 outputs per
-// workgroup, grid.y tiles of 128).
+// workgroup, grid.y tiles of 128); chunks of 64 (V <= 128) or 32 channels double-buffered in
+// LDS: while chunk k is multiplied, chunk k+1 -- of this contour or, when the grid is smaller
+// than n, of the workgroup's next contour -- is staged into registers and committed to the
+// other buffer at the chunk boundary.  With two chunks per contour (128 channels) both stay
+// resident, and the residual is read back from LDS in the epilogue.
 template <int RT>
-__global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a)
+__global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
 {
+    constexpr int CBC = RT <= 4 ? 8 : 4, NST = CBC / 2, AD = NST % 4 == 0 ? 4 : 2, NW = 4;
+    using G = Geo<RT, CBC>;
+    using S = StageGeo<RT, CBC, NW>;
     extern __shared__ __attribute__((aligned(16))) char xs[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const long long nn = blockIdx.x;
     const int o0 = blockIdx.y * 128 + wave * 32;
     const bool active = o0 < a.cout;
-    const int v = a.v, vp = v + 1;
-    const _Float16 *xn = a.x + nn * a.x_stride;
-    const int cbt = a.cin >> 3;
-    const long long wbs = a.cout, wts = (long long)cbt * a.cout, wps = (long long)a.taps * wts;
+    const int v = a.v;
+    const long long wbs_b = (long long)a.cout * 16, wts_b = (long long)(a.cin >> 3) * wbs_b,
+                    wps_b = (long long)a.taps * wts_b;
+    const unsigned wlane = (unsigned)(h * a.cout + r) * 16u;
+    const int nch = a.cin / (CBC * 8);
+    const bool res_lds = a.residual && nch <= 2;
+    const int ostep = gridDim.x;
 
-    f32x16 acc[1][RT];
-    if (active) {
-        init_acc16<RT, 1>(acc, a.rowinit ? a.rowinit + nn * a.cout : a.bias_s, o0, h);
-        if (a.rowinit) {
-            const float ws = 1.0f / a.winv;               // exact: a power of two
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                acc[0][rt] *= ws;
-        }
-    }
+    // byte pointer to (plane 0, first block) of chunk c of contour m
+    auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
+        const int c0 = c * CBC * 8;
+        return reinterpret_cast<const char *>(a.x + m * a.x_stride + (c0 >> 7) * a.x_slot_stride) +
+               (long long)((c0 & 127) >> 3) * v * 16;
+    };
 
-    for (int c0 = 0; c0 < a.cin; c0 += a.ck) {
-        const int ckn = min(a.ck, a.cin - c0);
-        const int cbc = ckn >> 3;
-        __syncthreads();
-        load_chunk_p16(xs, xn + (c0 >> 7) * a.x_slot_stride, v, vp, (c0 & 127) >> 3, cbc, wave, 4, lane);
-        __syncthreads();
-        if (active)
-            mfma16_chunk<RT, 1>(acc, xs, v, vp, cbc, a.w + ((long long)(c0 >> 3) + h) * wbs + o0 + r,
-                                wps, wts, wbs, 0, a.taps, a.dilation, r, h);
-    }
-    if (!active)
-        return;
-    // epilogue: lane = vertex column, register group g = channels 8g + 4h .. + 3 of the tile
-    const int cbc_last = min(a.ck, a.cin) >> 3;
-    _Float16 *yslot = a.y ? a.y + nn * a.y_stride + (o0 >> 7) * a.y_slot_stride : nullptr;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float sc[4], sh[4], mx[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = o0 + 8 * g + 4 * h + i;
-            sc[i] = a.scale ? a.scale[o] : 1.0f;
-            sh[i] = a.scale ? a.shift[o] : 0.0f;
-            mx[i] = -INFINITY;
+    u32x4 sreg[S::N];
+    long long nn = blockIdx.x;
+    stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane);
+    stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
+    __syncthreads();
+
+    int k = 0;
+    for (; nn < n; nn += ostep) {
+        f32x16 acc[1][RT];
+        if (active) {
+            // accumulators carry 2^s-scaled sums; a per-contour row start is scaled to match
+            if (a.rowinit)
+                init_acc16<RT, 1>(acc, a.rowinit + nn * a.cout, o0, h, 1.0f / a.winv);
+            else
+                init_acc16<RT, 1>(acc, a.bias_s, o0, h, 1.0f);
         }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int vv = rt * 32 + r;
-            if (vv >= v)
-                continue;
-            float val[4];
-            h4 rh, rl;
-            if (a.residual) {
-                // x itself (single-chunk image still in LDS): rows (o0/8 + g), halfs 4h..4h+3
-                const char *p = xs + ((long long)((o0 >> 3) + g) * vp + vv) * 16 + 8 * h;
-                rh = *reinterpret_cast<const h4 *>(p);
-                rl = *reinterpret_cast<const h4 *>(p + (long long)cbc_last * vp * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = acc[0][rt][4 * g + i] * a.winv;
-                if (a.relu)
-                    x = x > 0.0f ? x : (x != x ? x : 0.0f);
-                if (a.scale)
-                    x = x * sc[i] + sh[i];
-                if (a.residual)
-                    x += (float)rh[i] + (float)rl[i];
-                val[i] = x;
-                mx[i] = dance::nan_max(x, mx[i]);
-            }
-            if (a.maxv)
-                continue;
-            if (yslot) {
-                dance::store_p16(yslot, v, ((o0 & 127) >> 3) + g, vv, h, val);
+        for (int c = 0; c < nch; ++c, ++k) {
+            const unsigned cur = (k & 1) * G::BYTES, nxt = ((k + 1) & 1) * G::BYTES;
+            const bool last = c + 1 == nch;
+            const bool has_next = !last || nn + ostep < n;
+            // nothing left to stage: re-read the current chunk (valid memory), never committed
+            const char *ssrc = has_next ? chunk_src(last ? nn + ostep : nn, last ? 0 : c + 1) : chunk_src(nn, c);
+            if (active) {
+                auto hook = [&](int s) __attribute__((always_inline)) {
+                    stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
+                };
+                mfma16_core<RT, 1, NST, AD>(acc, xs, cur, v,
+                                            reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * a.cout + o0) * 16,
+                                            wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, hook);
             } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    a.yf[nn * a.yf_stride + (long long)(o0 + 8 * g + 4 * h + i) * v + vv] = val[i];
+                stage_load<RT, CBC, NW>(sreg, 0, S::N, ssrc, v, wave, lane);
             }
-        }
-        if (a.maxv) {
+            if (last && active) {
+                // epilogue: lane = vertex column, register group g = channels 8g+4h .. +3.
+                // (re, he) are r, h made opaque so that the compiler does not hoist the
+                // epilogue's addresses and per-channel constants above the MFMA chunks,
+                // where they would be live across them and spill.
+                int re = r, he = h;
+                asm volatile("" : "+v"(re), "+v"(he));
+                _Float16 *yslot = a.y ? a.y + nn * a.y_stride + (o0 >> 7) * a.y_slot_stride : nullptr;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float m = mx[i];
+                for (int g = 0; g < 4; ++g) {
+                    const int ob = o0 + 8 * g + 4 * he;
+                    float4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+                    if (a.scale) {
+                        sc4 = *reinterpret_cast<const float4 *>(a.scale + ob);
+                        sh4 = *reinterpret_cast<const float4 *>(a.shift + ob);
+                    }
+                    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+                    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    // residual source: input rows (o0 / 8 + g): LDS image (chunk = row / CBC) or global
+                    const int xrow = (o0 >> 3) + g;
+                    const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
+                    const unsigned rbuf = ((k - (nch - 1) + xchunk) & 1) * G::BYTES;
 #pragma unroll
-                for (int s = 16; s >= 1; s >>= 1)
-                    m = dance::nan_max(__shfl_xor(m, s, 64), m);
-                if (r == 0)
-                    a.yf[nn * a.cout + o0 + 8 * g + 4 * h + i] = m;
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int vv = rt * 32 + re;
+                        if (vv >= v)
+                            continue;
+                        float val[4];
+                        h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};
+                        if (a.residual) {
+                            if (res_lds) {
+                                const char *q = xs + rbuf + (xcbl * G::VP + vv) * 16 + 8 * he;
+                                rh = *reinterpret_cast<const h4 *>(q);
+                                rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
+                            } else {
+                                const _Float16 *q = a.x + nn * a.x_stride + ((long long)xrow * v + vv) * 8 + 4 * he;
+                                rh = *reinterpret_cast<const h4 *>(q);
+                                rl = *reinterpret_cast<const h4 *>(q + 128ll * v);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float x = acc[0][rt][4 * g + i] * a.winv;
+                            if (a.relu)
+                                x = relu_nan(x);
+                            if (a.scale)
+                                x = x * sc[i] + sh[i];
+                            if (a.residual)
+                                x += (float)rh[i] + (float)rl[i];
+                            val[i] = x;
+                        }
+                        if (a.maxv) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                mx[i] = dance::nan_max(val[i], mx[i]);
+                        } else if (yslot) {
+                            dance::store_p16(yslot, v, ((o0 & 127) >> 3) + g, vv, he, val);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                a.yf[nn * a.yf_stride + (long long)(ob + i) * v + vv] = val[i];
+                        }
+                    }
+                    if (a.maxv) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float m = mx[i];
+#pragma unroll
+                            for (int s = 16; s >= 1; s >>= 1)
+                                m = dance::nan_max(__shfl_xor(m, s, 64), m);
+                            if (re == 0)
+                                a.yf[nn * a.cout + ob + i] = m;
+                        }
+                    }
+                }
             }
+            __syncthreads();                    // every wave is done with chunk k (and the residual)
+            if (has_next)
+                stage_commit<RT, CBC, NW>(sreg, xs, nxt, v, wave, lane);
+            __syncthreads();
         }
     }
 }
@@ -242,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a)
 // fusion (1024 -> 256, max over the ring) + row constant + prediction[0] (1280 -> 256, ReLU)
 // in one pass over the 1024-channel state: 8 waves, two 32-channel tiles each; waves 0-3 own
 // the fusion outputs, waves 4-7 the prediction outputs (weights packed as one 512-output GEMM).
+// Chunks of 128 channels, double-buffered like k_conv16 (one staged load per step).
 struct Fuse16Args {
     const _Float16 *x;
     long long x_stride, x_slot_stride;
@@ -252,90 +378,116 @@ struct Fuse16Args {
     float winv;
     _Float16 *y;                  // P16, 2 slots
     long long y_stride, y_slot_stride;
-    int v, ck;
+    int v;
 };
 
 template <int RT>
-__global__ __launch_bounds__(512, 2) void k_fuse16(Fuse16Args a)
+__global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
 {
+    constexpr int CBC = 16, NST = 8, AD = 2, NW = 8, NCH = 1024 / (CBC * 8);
+    using G = Geo<RT, CBC>;
+    using S = StageGeo<RT, CBC, NW>;
     extern __shared__ __attribute__((aligned(16))) char xs[];
     __shared__ float gs[256];
     __shared__ float hp[512];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const long long nn = blockIdx.x;
     const int o0 = wave * 64;
-    const int v = a.v, vp = v + 1;
-    const _Float16 *xn = a.x + nn * a.x_stride;
-    const long long wbs = 512, wts = 128ll * 512, wps = wts;
+    const int v = a.v;
+    const long long wbs_b = 512 * 16, wts_b = 128 * wbs_b;
+    const unsigned wlane = (unsigned)(h * 512 + r) * 16u;
+    const int ostep = gridDim.x;
 
-    f32x16 acc[2][RT];
-    init_acc16<RT, 2>(acc, a.bias_s, o0, h);
-    for (int c0 = 0; c0 < 1024; c0 += a.ck) {
-        const int cbc = a.ck >> 3;
-        __syncthreads();
-        load_chunk_p16(xs, xn + (c0 >> 7) * a.x_slot_stride, v, vp, (c0 & 127) >> 3, cbc, wave, 8, lane);
-        __syncthreads();
-        mfma16_chunk<RT, 2>(acc, xs, v, vp, cbc, a.w + ((long long)(c0 >> 3) + h) * wbs + o0 + r, wps,
-                            wts, wbs, 32, 1, 1, r, h);
-    }
-    if (wave < 4) {
-        // global state = max over the ring of the fusion output (snake_head.py:271-272)
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float m = -INFINITY;
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    if (rt * 32 + r < v)
-                        m = dance::nan_max(acc[ot][rt][q] * a.winv, m);
-#pragma unroll
-                for (int s = 16; s >= 1; s >>= 1)
-                    m = dance::nan_max(__shfl_xor(m, s, 64), m);
-                if (r == 0)
-                    gs[o0 + ot * 32 + (q & 3) + 8 * (q >> 2) + 4 * h] = m;
-            }
-    }
+    auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
+        return reinterpret_cast<const char *>(a.x + m * a.x_stride + c * a.x_slot_stride);
+    };
+
+    u32x4 sreg[S::N];
+    long long nn = blockIdx.x;
+    stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane);
+    stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
     __syncthreads();
-    {   // row constant h[o] = pb[o] + sum_g wg[g][o] * G[g], two half sums per output
-        const int o = t & 255, half = t >> 8;
-        float s = 0.0f;
-        const float *wgp = a.wg + (long long)half * 128 * 256 + o;
-#pragma unroll 8
-        for (int k = 0; k < 128; ++k)
-            s = fmaf(wgp[(long long)k * 256], gs[half * 128 + k], s);
-        hp[t] = s;
-    }
-    __syncthreads();
-    if (wave >= 4) {
-        const int p0 = o0 - 256;                        // prediction output channel of tile 0
-        _Float16 *yn = a.y + nn * a.y_stride;
+
+    int k = 0;
+    for (; nn < n; nn += ostep) {
+        f32x16 acc[2][RT];
+        init_acc16<RT, 2>(acc, a.bias_s, o0, h, 1.0f);
+        for (int c = 0; c < NCH; ++c, ++k) {
+            const unsigned cur = (k & 1) * G::BYTES, nxt = ((k + 1) & 1) * G::BYTES;
+            const bool last = c + 1 == NCH;
+            const bool has_next = !last || nn + ostep < n;
+            const char *ssrc = has_next ? chunk_src(last ? nn + ostep : nn, last ? 0 : c + 1) : chunk_src(nn, c);
+            auto hook = [&](int s) __attribute__((always_inline)) {
+                stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
+            };
+            mfma16_core<RT, 2, NST, AD>(acc, xs, cur, v,
+                                        reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * 512 + o0) * 16,
+                                        wlane, wts_b, wts_b, 2 * wbs_b, 1, 1, r, h, hook);
+            __syncthreads();
+            if (has_next)
+                stage_commit<RT, CBC, NW>(sreg, xs, nxt, v, wave, lane);
+            __syncthreads();
+        }
+        int re = r, he = h;
+        asm volatile("" : "+v"(re), "+v"(he));
+        if (wave < 4) {
+            // global state = max over the ring of the fusion output (snake_head.py:271-272)
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot)
+            for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float hc[4];
+                for (int q = 0; q < 16; ++q) {
+                    float m = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int o = p0 + ot * 32 + 8 * g + 4 * h + i;
-                    hc[i] = a.pb[o] + hp[o] + hp[256 + o];
+                    for (int rt = 0; rt < RT; ++rt)
+                        if (rt * 32 + re < v)
+                            m = dance::nan_max(acc[ot][rt][q] * a.winv, m);
+#pragma unroll
+                    for (int s = 16; s >= 1; s >>= 1)
+                        m = dance::nan_max(__shfl_xor(m, s, 64), m);
+                    if (re == 0)
+                        gs[o0 + ot * 32 + (q & 3) + 8 * (q >> 2) + 4 * he] = m;
                 }
-                const int ob = p0 + ot * 32 + 8 * g;
+        }
+        __syncthreads();
+        {   // row constant h[o] = pb[o] + sum_g wg[g][o] * G[g], two half sums per output
+            const int o = t & 255, half = t >> 8;
+            float s = 0.0f;
+            const float *wgp = a.wg + (long long)half * 128 * 256 + o;
+#pragma unroll 8
+            for (int kk = 0; kk < 128; ++kk)
+                s = fmaf(wgp[(long long)kk * 256], gs[half * 128 + kk], s);
+            hp[t] = s;
+        }
+        __syncthreads();
+        if (wave >= 4) {
+            const int p0 = o0 - 256;                        // prediction output channel of tile 0
+            _Float16 *yn = a.y + nn * a.y_stride;
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    const int vv = rt * 32 + r;
-                    if (vv >= v)
-                        continue;
-                    float val[4];
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float hc[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float x = acc[ot][rt][4 * g + i] * a.winv + hc[i];
-                        val[i] = x > 0.0f ? x : (x != x ? x : 0.0f);
+                        const int o = p0 + ot * 32 + 8 * g + 4 * he + i;
+                        hc[i] = a.pb[o] + hp[o] + hp[256 + o];
                     }
-                    dance::store_p16(yn + (ob >> 7) * a.y_slot_stride, v, (ob & 127) >> 3, vv, h, val);
+                    const int ob = p0 + ot * 32 + 8 * g;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int vv = rt * 32 + re;
+                        if (vv >= v)
+                            continue;
+                        float val[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            val[i] = relu_nan(acc[ot][rt][4 * g + i] * a.winv + hc[i]);
+                        dance::store_p16(yn + (ob >> 7) * a.y_slot_stride, v, (ob & 127) >> 3, vv, he, val);
+                    }
                 }
-            }
+        }
+        // gs / hp are rewritten only after the next contour's chunk barriers
     }
 }
 
@@ -352,16 +504,19 @@ struct Gather16Args {
 template <int RT>
 __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16Args g)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int v = a.v, vp = v + 1;
     constexpr int CBC = 8;                                      // 64 channels per chunk
-    char *xs = smem;                                            // [2][8][vp] words
-    float *tw = reinterpret_cast<float *>(smem + 2 * CBC * vp * 16);   // [v][4]
+    using G = Geo<RT, CBC>;
+    using GD = Geo<RT, 4>;                                      // de_location chunk: 32 channels
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int v = a.v;
+    char *xs = smem;                                            // one chunk image
+    float *tw = reinterpret_cast<float *>(smem + G::BYTES);     // [v][4]
     int *toff = reinterpret_cast<int *>(tw + 4 * v);            // [v][4]
     float *dl = reinterpret_cast<float *>(toff + 4 * v);        // [2][v]
     float *red = dl + 2 * v;                                    // [16]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
     const long long nn = blockIdx.x;
     const int o0 = wave * 32;
@@ -400,73 +555,74 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
     }
 
     f32x16 acc[1][RT];
-    init_acc16<RT, 1>(acc, a.bias_s, o0, h);
-    const int cbt = a.cin >> 3;                                 // padded input channels / 8
-    const long long wbs = a.cout, wts = (long long)cbt * a.cout, wps = (long long)a.taps * wts;
+    init_acc16<RT, 1>(acc, a.bias_s, o0, h, 1.0f);
+    const long long wbs_b = (long long)a.cout * 16, wts_b = (long long)(a.cin >> 3) * wbs_b,
+                    wps_b = (long long)a.taps * wts_b;
+    const unsigned wlane = (unsigned)(h * a.cout + r) * 16u;
     const float *fimg = g.feat + img * plane * g.c;
     const int lc = t & 15, vs = t >> 4;                         // 16 lanes x float4 = 64 channels
-    const int c_end = g.c + (g.deloc != DANCE_DELOC_NONE ? 16 : 0);
-    for (int c0 = 0; c0 < c_end; c0 += 64) {
+    auto nohook = [](int) __attribute__((always_inline)) {};
+    for (int c0 = 0; c0 < g.c; c0 += 64) {
         __syncthreads();
-        int cbc = CBC;
-        if (c0 < g.c) {
 #pragma unroll 2
-            for (int s = vs; s < v; s += 16) {
+        for (int s = vs; s < v; s += 16) {
 #pragma clang fp contract(off)
-                const float w0 = tw[s * 4 + 0], w1 = tw[s * 4 + 1], w2 = tw[s * 4 + 2], w3 = tw[s * 4 + 3];
-                const int ch = c0 + 4 * lc;
-                const float4 a0 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 0] * g.c + ch);
-                const float4 a1 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 1] * g.c + ch);
-                const float4 a2 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 2] * g.c + ch);
-                const float4 a3 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 3] * g.c + ch);
-                float val[4];
-                val[0] = a0.x * w0 + a1.x * w1 + a2.x * w2 + a3.x * w3;
-                val[1] = a0.y * w0 + a1.y * w1 + a2.y * w2 + a3.y * w3;
-                val[2] = a0.z * w0 + a1.z * w1 + a2.z * w2 + a3.z * w3;
-                val[3] = a0.w * w0 + a1.w * w1 + a2.w * w2 + a3.w * w3;
-                h4 hi, lo;
+            const float w0 = tw[s * 4 + 0], w1 = tw[s * 4 + 1], w2 = tw[s * 4 + 2], w3 = tw[s * 4 + 3];
+            const int ch = c0 + 4 * lc;
+            const float4 a0 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 0] * g.c + ch);
+            const float4 a1 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 1] * g.c + ch);
+            const float4 a2 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 2] * g.c + ch);
+            const float4 a3 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 3] * g.c + ch);
+            float val[4];
+            val[0] = a0.x * w0 + a1.x * w1 + a2.x * w2 + a3.x * w3;
+            val[1] = a0.y * w0 + a1.y * w1 + a2.y * w2 + a3.y * w3;
+            val[2] = a0.z * w0 + a1.z * w1 + a2.z * w2 + a3.z * w3;
+            val[3] = a0.w * w0 + a1.w * w1 + a2.w * w2 + a3.w * w3;
+            h4 hi, lo;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    _Float16 p, q;
-                    dance::split_half(val[i], p, q);
-                    hi[i] = p;
-                    lo[i] = q;
-                }
-                char *d = xs + ((long long)(lc >> 1) * vp + s) * 16 + 8 * (lc & 1);
-                *reinterpret_cast<h4 *>(d) = hi;
-                *reinterpret_cast<h4 *>(d + CBC * vp * 16) = lo;
+            for (int i = 0; i < 4; ++i) {
+                _Float16 p, q;
+                dance::split_half(val[i], p, q);
+                hi[i] = p;
+                lo[i] = q;
             }
-        } else {
-            // de_location chunk: 2 blocks; block 0 = {dx, dy, 0 x 6}, block 1 = zeros
-            cbc = 2;
-            for (int i = t; i < 2 * v; i += 256) {
-                const int blk = i >= v ? 1 : 0, vi = i - blk * v;
-                h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (blk == 0) {
-                    _Float16 p, q;
-                    dance::split_half(dl[vi], p, q);
-                    hi[0] = p; lo[0] = q;
-                    dance::split_half(dl[v + vi], p, q);
-                    hi[1] = p; lo[1] = q;
-                }
-                *reinterpret_cast<h8 *>(xs + ((long long)blk * vp + vi) * 16) = hi;
-                *reinterpret_cast<h8 *>(xs + ((long long)(2 + blk) * vp + vi) * 16) = lo;
-            }
+            char *d = xs + ((lc >> 1) * G::VP + s) * 16 + 8 * (lc & 1);
+            *reinterpret_cast<h4 *>(d) = hi;
+            *reinterpret_cast<h4 *>(d + G::PLANE) = lo;
         }
         __syncthreads();
-        mfma16_chunk<RT, 1>(acc, xs, v, vp, cbc, a.w + ((long long)(c0 >> 3) + h) * wbs + o0 + r, wps,
-                            wts, wbs, 0, a.taps, a.dilation, r, h);
+        mfma16_core<RT, 1, 4, 4>(acc, xs, 0, v,
+                                 reinterpret_cast<const char *>(a.w) + ((long long)(c0 >> 3) * a.cout + o0) * 16,
+                                 wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
+    }
+    if (g.deloc != DANCE_DELOC_NONE) {
+        // de_location chunk: 4 blocks (weights zero-padded to 32 channels);
+        // block 0 = {dx, dy, 0 x 6}, blocks 1..3 = zeros
+        __syncthreads();
+        for (int i = t; i < 4 * v; i += 256) {
+            const int blk = i / v, vi = i - blk * v;
+            h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (blk == 0) {
+                _Float16 p, q;
+                dance::split_half(dl[vi], p, q);
+                hi[0] = p; lo[0] = q;
+                dance::split_half(dl[v + vi], p, q);
+                hi[1] = p; lo[1] = q;
+            }
+            *reinterpret_cast<h8 *>(xs + (blk * GD::VP + vi) * 16) = hi;
+            *reinterpret_cast<h8 *>(xs + GD::PLANE + (blk * GD::VP + vi) * 16) = lo;
+        }
+        __syncthreads();
+        mfma16_core<RT, 1, 2, 2>(acc, xs, 0, v,
+                                 reinterpret_cast<const char *>(a.w) + ((long long)(g.c >> 3) * a.cout + o0) * 16,
+                                 wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
     }
     _Float16 *yslot = a.y + nn * a.y_stride;
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-        float sc[4], sh[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = o0 + 8 * gq + 4 * h + i;
-            sc[i] = a.scale[o];
-            sh[i] = a.shift[o];
-        }
+        const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale + o0 + 8 * gq + 4 * h);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift + o0 + 8 * gq + 4 * h);
+        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int vv = rt * 32 + r;
@@ -474,11 +630,8 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
                 continue;
             float val[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x = acc[0][rt][4 * gq + i] * a.winv;
-                x = x > 0.0f ? x : (x != x ? x : 0.0f);
-                val[i] = x * sc[i] + sh[i];
-            }
+            for (int i = 0; i < 4; ++i)
+                val[i] = relu_nan(acc[0][rt][4 * gq + i] * a.winv) * sc[i] + sh[i];
             dance::store_p16(yslot, v, (o0 >> 3) + gq, vv, h, val);
         }
     }
@@ -486,13 +639,19 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
 
 int pick_rt16(int v) { return v <= 64 ? 2 : (v <= 128 ? 4 : (v <= 224 ? 7 : 8)); }
 
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 template <typename K>
 int big_lds(K kernel, size_t bytes, const char *fn)
 {
     if (bytes <= 64 * 1024)
         return 0;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
+                                       (int)bytes);
     return e == hipSuccess ? 0 : dance::fail((int)e, fn, hipGetErrorString(e));
 }
 
@@ -519,7 +678,7 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
                             void *stream)
 {
     DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
-    DANCE_REQUIRE(cin >= 16 && cin % 16 == 0 && (cin <= 128 || cin % 128 == 0));
+    DANCE_REQUIRE(cin >= 32 && cin % 32 == 0 && (cin <= 128 || cin % 128 == 0));
     DANCE_REQUIRE(cout >= 32 && cout % 32 == 0);
     DANCE_REQUIRE(taps == 1 || taps == 9);
     DANCE_REQUIRE(dilation >= 1 && dilation * (taps / 2) <= 16);
@@ -537,12 +696,16 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
     DANCE_REQUIRE(!maxv || (y_f32 && !residual));
     DANCE_REQUIRE(rowinit || bias_scaled);
     DANCE_REQUIRE(!scale || shift);
-    // whole input in LDS when it is a single slot (needed for the LDS residual); else 64-ch chunks
-    a.ck = cin <= 128 ? cin : 64;
     DANCE_REQUIRE(!residual || (cin == cout && cin <= 128));
-    const size_t lds = (size_t)2 * (a.ck / 8) * (v + 1) * 16;
-    dim3 grid(n, dance::ceil_div(cout, 128));
-    LAUNCH_RT(k_conv16, pick_rt16(v), grid, dim3(256), lds, (hipStream_t)stream, "dance_conv16", a);
+    const int rt = pick_rt16(v);
+    const int cbc = rt <= 4 ? 8 : 4;                           // k_conv16's CBC
+    DANCE_REQUIRE(cin % (cbc * 8) == 0);
+    const size_t lds = (size_t)2 * 2 * cbc * (rt * 32 + 1) * 16;   // two chunk images
+    // one workgroup per contour by default (the dispatcher balances them); a smaller grid
+    // makes workgroups persistent over contours nn, nn + grid, ... (tuning knob)
+    const int slots = env_int("DANCE_CONV16_SLOTS", 0);
+    dim3 grid(slots > 0 && slots < n ? slots : n, dance::ceil_div(cout, 128));
+    LAUNCH_RT(k_conv16, rt, grid, dim3(256), lds, (hipStream_t)stream, "dance_conv16", a, n);
     return launch_check(__func__);
 }
 
@@ -559,13 +722,23 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     a.x = (const _Float16 *)x; a.x_stride = x_stride; a.x_slot_stride = x_slot_stride;
     a.w = (const h8 *)w16; a.bias_s = bias_scaled; a.wg = wg; a.pb = pred_bias; a.winv = w_inv_scale;
     a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
-    a.ck = 64;
-    const size_t lds = (size_t)2 * (a.ck / 8) * (v + 1) * 16;
     DANCE_REQUIRE(v <= 128);        // larger rings: unfused dance_conv16 sequence (accumulators)
-    if (v <= 64)
-        hipLaunchKernelGGL(k_fuse16<2>, dim3(n), dim3(512), lds, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(k_fuse16<4>, dim3(n), dim3(512), lds, (hipStream_t)stream, a);
+    const int rt = v <= 64 ? 2 : 4;
+    const size_t lds = (size_t)2 * 2 * 16 * (rt * 32 + 1) * 16;    // two 128-channel chunk images
+    const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
+    dim3 grid(slots > 0 && slots < n ? slots : n);
+    int rc = 0;
+    if (rt == 2) {
+        rc = big_lds(k_fuse16<2>, lds, __func__);
+        if (!rc)
+            hipLaunchKernelGGL(k_fuse16<2>, grid, dim3(512), lds, (hipStream_t)stream, a, n);
+    } else {
+        rc = big_lds(k_fuse16<4>, lds, __func__);
+        if (!rc)
+            hipLaunchKernelGGL(k_fuse16<4>, grid, dim3(512), lds, (hipStream_t)stream, a, n);
+    }
+    if (rc)
+        return rc;
     return launch_check(__func__);
 }
 
@@ -587,14 +760,15 @@ extern "C" int dance_gather_head16(const float *feat, const float *att, const fl
     a.x = nullptr; a.x_stride = 0; a.x_slot_stride = 0; a.w = (const h8 *)w16; a.bias_s = bias_scaled;
     a.scale = scale; a.shift = shift; a.winv = w_inv_scale; a.y = (_Float16 *)y16; a.y_stride = y_stride;
     a.y_slot_stride = 0; a.yf = nullptr; a.yf_stride = 0; a.v = v;
-    a.cin = (c + (deloc_type != DANCE_DELOC_NONE ? 2 : 0) + 15) & ~15; a.cout = 128; a.taps = 9;
-    a.dilation = 1; a.ck = 64; a.relu = 1; a.residual = 0; a.rowinit = nullptr; a.maxv = 0;
+    a.cin = (c + (deloc_type != DANCE_DELOC_NONE ? 2 : 0) + 31) & ~31; a.cout = 128; a.taps = 9;
+    a.dilation = 1; a.relu = 1; a.residual = 0; a.rowinit = nullptr; a.maxv = 0;
     Gather16Args g;
     g.feat = feat; g.att = att; g.loc = loc; g.image_idx = image_idx; g.att_out = att_out; g.b = b;
     g.hf = hf; g.wf = wf; g.c = c; g.reflection = padding_mode == DANCE_PAD_REFLECTION;
     g.deloc = deloc_type;
-    const size_t lds = (size_t)2 * 8 * (v + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
-    LAUNCH_RT(k_gather_head16, pick_rt16(v), dim3(n), dim3(256), lds, (hipStream_t)stream,
+    const int rt = pick_rt16(v);
+    const size_t lds = (size_t)2 * 8 * (rt * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
+    LAUNCH_RT(k_gather_head16, rt, dim3(n), dim3(256), lds, (hipStream_t)stream,
               "dance_gather_head16", a, g);
     return launch_check(__func__);
 }

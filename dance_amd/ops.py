@@ -114,10 +114,11 @@ def pack_conv_weight(weight):
 
 def pack_conv_weight16(weight):
     """Conv1d weight (Cout, Cin, K) -> split-half packing for the fast precision mode:
-    (2, K, Cin_pad16/8, Cout, 8) fp16 = hi/lo planes of w * 2^s, plus 2^s.  The power-of-two
-    scale keeps the lo halves normal fp16 numbers and is undone exactly in the epilogue."""
+    (2, K, Cin_pad32/8, Cout, 8) fp16 = hi/lo planes of w * 2^s, plus 2^s.  The power-of-two
+    scale keeps the lo halves normal fp16 numbers and is undone exactly in the epilogue.
+    Input channels are zero-padded to a multiple of 32 (the kernels' smallest chunk)."""
     cout, cin, k = weight.shape
-    cin_pad = (cin + 15) // 16 * 16
+    cin_pad = (cin + 31) // 32 * 32
     w = torch.zeros((cout, cin_pad, k), dtype=torch.float32, device=weight.device)
     w[:, :cin, :] = weight.float()
     amax = float(w.abs().max())
