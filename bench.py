@@ -33,6 +33,7 @@ MACS_RES_BLOCK = 128 * 128 * 9
 MACS_PER_VERTEX = (CH + 2) * 128 * 9 + 7 * MACS_RES_BLOCK + 1024 * 256 + 1280 * 256 + 256 * 64 + 64 * 2
 GATHER_BYTES_PER_VERTEX = 4 * (CH + 1) * 4            # 4 taps x 257 channels x fp32
 PEAK_F32_MFMA_TFLOPS = 157.3                          # MI355X_MICROARCH.md, f32-input MFMA
+PEAK_F16_MFMA_TFLOPS = 2500.0                         # MI355X_MICROARCH.md, BF16/FP16 dense
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -47,6 +48,9 @@ def parse():
     ap.add_argument("--layout", choices=("nchw", "nhwc"), default="nchw",
                     help="nchw (default): the layout pass is inside the timed step")
     ap.add_argument("--no-fused-head", action="store_true")
+    ap.add_argument("--precision", choices=("fp16x3", "fp32"), default="fp16x3",
+                    help="fp16x3 (default): split-half operands, 3 f16 MFMAs per product, fp32 "
+                         "accumulate (fp32-level accuracy); fp32: exact-fp32 MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     return ap.parse_args()
@@ -104,7 +108,7 @@ def main():
     sd = {k: t.clone() for k, t in modules.RefineNet(cfg).state_dict().items()}
     synthetic.fill_state_dict_(sd, 1234)
     nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), dev) for i in range(ITERS)]
-    deformer = snake.ContourDeformer(nets, fused_head=not args.no_fused_head)
+    deformer = snake.ContourDeformer(nets, fused_head=not args.no_fused_head, precision=args.precision)
     deformer.MAX_CHUNK = max(deformer.MAX_CHUNK, n)          # one kernel sequence per iteration
 
     # synthetic inputs, resident in HBM before the timed region
@@ -171,36 +175,54 @@ def main():
                     stage_ms[s] += ev[s].elapsed_time(ev[s + 1])
         launches = args.steps * ITERS
         stage_avg = {name: stage_ms[i] / launches for i, name in enumerate(STAGE_NAMES)}
-        res_ms = sum(stage_avg["res%d" % i] for i in range(7)) / 7.0       # one k_circconv launch
-        res_flops = 2.0 * MACS_RES_BLOCK * v * n
+        res_ms = sum(stage_avg["res%d" % i] for i in range(7)) / 7.0       # one residual-block launch
+        res_tflops = 2.0 * MACS_RES_BLOCK * v * n / (res_ms * 1e-3) / 1e12  # algorithmic
         head_ms = stage_avg["head"]
         gather_gbps = GATHER_BYTES_PER_VERTEX * v * n / (head_ms * 1e-3) / 1e9
         layout_ms = (sum(a.elapsed_time(b_) for a, b_ in layout_ev) / args.steps) if pre is None else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         total_flops = 2.0 * MACS_PER_VERTEX * v * n * ITERS
+        rt = 2 if v <= 64 else 4 if v <= 128 else 7 if v <= 224 else 8
+        if args.precision == "fp16x3":
+            # every algorithmic product is three f16 MFMA products (A_lo*B_hi + A_hi*B_lo +
+            # A_hi*B_hi); the roofline prices the EXECUTED f16 MFMA flops against the f16 peak
+            roof = {"kernel": "k_conv16<%d> (residual SnakeBlock 128->128, k=9, split-half f16 MFMA)" % rt,
+                    "bound": "mfma", "achieved": 3.0 * res_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": 3.0 * res_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_ms": res_ms, "algorithmic_TFLOPs": res_tflops, "mfma_per_product": 3,
+                    "note": "achieved = executed f16 MFMA flops (3 x algorithmic) / HIP-event launch time"}
+            dtype = "f16x3/f32acc"
+            gkernel = "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt
+        else:
+            roof = {"kernel": "k_circconv<%d> (residual SnakeBlock 128->128, k=9, f32 MFMA)" % rt,
+                    "bound": "mfma", "achieved": res_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": res_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_ms": res_ms, "algorithmic_TFLOPs": res_tflops, "mfma_per_product": 1}
+            dtype = "f32"
+            gkernel = "k_gather_head<%d> (fused gather + head SnakeBlock)" % rt
         line = {
             "metric": "contours deformed/sec (128 vertices, all iters)",
             "value": world * n * args.steps / elapsed,
             "unit": "contours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: DANCE R50 snake head fp32, %d images x %d "
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: DANCE R50 snake head, %d images x %d "
                                    "instances x %d vertices per GPU, %d iterations, features "
-                                   "(%d,%d,%d,%d) %s in HBM" % (b, per, v, ITERS, b, CH + 1, HF, WF,
-                                                                args.layout.upper()),
+                                   "(%d,%d,%d,%d) %s fp32 in HBM" % (b, per, v, ITERS, b, CH + 1, HF, WF,
+                                                                     args.layout.upper()),
                        "contours_per_gpu": n, "vertices": v, "iterations": ITERS,
+                       "precision": args.precision + (" (fp32-level accuracy: parity 1e-4 norm-wise per "
+                                                      "iteration vs the fp32 reference)"
+                                                      if args.precision == "fp16x3" else " (exact f32 MFMA)"),
                        "fused_head": not args.no_fused_head, "parallelism": "dp%d" % world},
-            "roofline": {"kernel": "k_circconv<4> (residual SnakeBlock 128->128, k=9)",
-                         "bound": "mfma", "achieved": res_flops / (res_ms * 1e-3) / 1e12,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": res_flops / (res_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": res_ms},
-            "gather": {"kernel": "k_gather_head<4> (fused gather + head SnakeBlock)",
+            "roofline": roof,
+            "gather": {"kernel": gkernel,
                        "algorithmic_GBps": gather_gbps, "frac_of_hbm_peak": gather_gbps / PEAK_HBM_GBPS,
                        "avg_launch_ms": head_ms,
-                       "note": "fused kernel is MFMA-bound in fp32 (76 MFLOP per 526 KB contour-iteration)"},
-            "whole_path_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
+                       "note": "the fused kernel is MFMA-bound (85 MFLOP per 526 KB gathered per "
+                               "contour-iteration), not HBM-bound"},
+            "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/dance_hip.h"
 
@@ -28,6 +29,16 @@ inline int launch_check(const char *fn)
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(<E - 1>)
+template <int B, int E, typename F>
+__host__ __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 }  // namespace dance
 

@@ -73,16 +73,19 @@ struct Geo {
 //   wps_b / wts_b / wstep_b : byte strides of a plane / a tap / two channel blocks (one step)
 //   hook(s)     : called once per step of tap 0, after the step's weight prefetch was issued
 //                 (the place for staged activation loads)
-// AD weight buffers rotate (prefetch distance AD - 1 steps); B tiles ping-pong one tile ahead.
-template <int RT, int OTW, int NST, int AD, typename Hook>
+// AD weight buffers rotate (prefetch distance AD - 1 steps); NB vertex-tile (B) buffers rotate
+// over the flat tile sequence q = s * RT + rt (prefetch distance NB - 1 tiles).
+template <int RT, int OTW, int NST, int AD, int NB, typename Hook>
 __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *xs, unsigned lds0, int v,
                                             const char *wchunk, unsigned wlane, long long wps_b,
                                             long long wts_b, long long wstep_b, int taps, int dilation,
                                             int r, int h, Hook hook)
 {
-    static_assert(RT >= 2 && NST % AD == 0 && (NST * RT) % 2 == 0 && AD - 1 <= NST, "rotation parity");
+    constexpr int NT = NST * RT, DB = NB - 1, D = AD - 1;
+    static_assert(NST % AD == 0 && D <= NST, "weight buffer rotation must close over a tap");
+    static_assert(NT % NB == 0 && DB <= NT - RT && DB >= 1, "tile buffer rotation must close over a tap");
     using G = Geo<RT, 2 * NST>;
-    constexpr int SSTEP = 2 * G::VP * 16, D = AD - 1;
+    constexpr int SSTEP = 2 * G::VP * 16;
     const unsigned rowb = lds0 + h * G::VP * 16;
     const unsigned lim = rowb + v * 16, d16 = dilation * 16, v16 = v * 16;
     unsigned p[RT];                             // LDS byte address of this lane's word, per vertex tile
@@ -99,59 +102,55 @@ __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *
             al[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + ot_ * 512);       \
         }                                                                                         \
     } while (0)
+    // tile Q of the current tap (Q < NT) or of the next one (p[] of its vertex tile already
+    // advanced); p[rt] advances right after its last use in a tap (the fetch of step NST - 1)
+#define DANCE_LOAD_B(Q)                                                                           \
+    do {                                                                                          \
+        constexpr int q_ = (Q) % NT, s_ = q_ / RT, rt_ = q_ % RT;                                 \
+        bh[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[rt_] + s_ * SSTEP);                   \
+        bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[rt_] + s_ * SSTEP + G::PLANE);        \
+        if (s_ == NST - 1) {                                                                      \
+            const unsigned tpos_ = p[rt_] + d16;                                                  \
+            p[rt_] = tpos_ >= lim ? tpos_ - v16 : tpos_;                                          \
+        }                                                                                         \
+    } while (0)
 #pragma unroll
     for (int q = 0; q < D; ++q)
         DANCE_LOAD_A(q, wchunk + q * wstep_b);
-    h8 bh[2], bl[2];
-    bh[0] = *reinterpret_cast<const h8 *>(xs + p[0]);
-    bl[0] = *reinterpret_cast<const h8 *>(xs + p[0] + G::PLANE);
+    h8 bh[NB], bl[NB];
+    dance::static_for<0, DB>([&](auto q) __attribute__((always_inline)) { DANCE_LOAD_B(decltype(q)::value); });
 
     const char *wtap = wchunk;
     for (int tap = 0; tap < taps; ++tap) {
         const bool more = tap + 1 < taps;
-#pragma unroll
-        for (int s = 0; s < NST; ++s) {
-            if (s + D < NST)
-                DANCE_LOAD_A((s + D) % AD, wtap + (s + D) * wstep_b);
-            else if (more)
-                DANCE_LOAD_A((s + D) % AD, wtap + wts_b + (s + D - NST) * wstep_b);
-            if (tap == 0)
-                hook(s);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int cur = (s * RT + rt) & 1, nx = cur ^ 1;
-                // next tile: same step, next step, or step 0 of the next tap (p[0] already advanced)
-                if (rt + 1 < RT) {
-                    bh[nx] = *reinterpret_cast<const h8 *>(xs + p[rt + 1] + s * SSTEP);
-                    bl[nx] = *reinterpret_cast<const h8 *>(xs + p[rt + 1] + s * SSTEP + G::PLANE);
-                } else if (s + 1 < NST) {
-                    bh[nx] = *reinterpret_cast<const h8 *>(xs + p[0] + (s + 1) * SSTEP);
-                    bl[nx] = *reinterpret_cast<const h8 *>(xs + p[0] + (s + 1) * SSTEP + G::PLANE);
-                } else {
-                    bh[nx] = *reinterpret_cast<const h8 *>(xs + p[0]);
-                    bl[nx] = *reinterpret_cast<const h8 *>(xs + p[0] + G::PLANE);
-                }
-                // keep the prefetch ahead of this tile's MFMAs (the scheduler otherwise sinks
-                // it below them and the ping-pong collapses into load -> wait -> use)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ot = 0; ot < OTW; ++ot)
-                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % AD][ot], bh[cur], acc[ot][rt], 0, 0, 0);
-#pragma unroll
-                for (int ot = 0; ot < OTW; ++ot)
-                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bl[cur], acc[ot][rt], 0, 0, 0);
-#pragma unroll
-                for (int ot = 0; ot < OTW; ++ot)
-                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bh[cur], acc[ot][rt], 0, 0, 0);
-                if (s == NST - 1) {             // tile rt of this tap was fetched: advance to the next tap
-                    const unsigned tpos = p[rt] + d16;
-                    p[rt] = tpos >= lim ? tpos - v16 : tpos;
-                }
+        dance::static_for<0, NT>([&](auto qq) __attribute__((always_inline)) {
+            constexpr int q = decltype(qq)::value, s = q / RT, rt = q % RT;
+            if constexpr (rt == 0) {
+                if (s + D < NST)
+                    DANCE_LOAD_A((s + D) % AD, wtap + (s + D) * wstep_b);
+                else if (more)
+                    DANCE_LOAD_A((s + D) % AD, wtap + wts_b + (s + D - NST) * wstep_b);
+                if (tap == 0)
+                    hook(s);
             }
-        }
+            DANCE_LOAD_B(q + DB);
+            // keep the prefetch ahead of this tile's MFMAs (the scheduler otherwise sinks it
+            // below them and the rotation collapses into load -> wait -> use)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ot = 0; ot < OTW; ++ot)
+                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % AD][ot], bh[q % NB], acc[ot][rt], 0, 0, 0);
+#pragma unroll
+            for (int ot = 0; ot < OTW; ++ot)
+                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bl[q % NB], acc[ot][rt], 0, 0, 0);
+#pragma unroll
+            for (int ot = 0; ot < OTW; ++ot)
+                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bh[q % NB], acc[ot][rt], 0, 0, 0);
+        });
         wtap += wts_b;
     }
 #undef DANCE_LOAD_A
+#undef DANCE_LOAD_B
 }
 
 // Staging of the next chunk image: this wave's rows (wave, wave + NW, ...), lanes along the
@@ -225,6 +224,7 @@ template <int RT>
 __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
 {
     constexpr int CBC = RT <= 4 ? 8 : 4, NST = CBC / 2, AD = NST % 4 == 0 ? 4 : 2, NW = 4;
+    constexpr int NB = RT <= 4 ? 4 : 2;
     using G = Geo<RT, CBC>;
     using S = StageGeo<RT, CBC, NW>;
     extern __shared__ __attribute__((aligned(16))) char xs[];
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
                 auto hook = [&](int s) __attribute__((always_inline)) {
                     stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
                 };
-                mfma16_core<RT, 1, NST, AD>(acc, xs, cur, v,
+                mfma16_core<RT, 1, NST, AD, NB>(acc, xs, cur, v,
                                             reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * a.cout + o0) * 16,
                                             wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, hook);
             } else {
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
 // fusion (1024 -> 256, max over the ring) + row constant + prediction[0] (1280 -> 256, ReLU)
 // in one pass over the 1024-channel state: 8 waves, two 32-channel tiles each; waves 0-3 own
 // the fusion outputs, waves 4-7 the prediction outputs (weights packed as one 512-output GEMM).
-// Chunks of 128 channels, double-buffered like k_conv16 (one staged load per step).
+// Chunks of 64 channels, double-buffered like k_conv16 (one staged load per step).
 struct Fuse16Args {
     const _Float16 *x;
     long long x_stride, x_slot_stride;
@@ -384,7 +384,7 @@ struct Fuse16Args {
 template <int RT>
 __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
 {
-    constexpr int CBC = 16, NST = 8, AD = 2, NW = 8, NCH = 1024 / (CBC * 8);
+    constexpr int CBC = 8, NST = 4, AD = 2, NW = 8, NCH = 1024 / (CBC * 8);
     using G = Geo<RT, CBC>;
     using S = StageGeo<RT, CBC, NW>;
     extern __shared__ __attribute__((aligned(16))) char xs[];
@@ -400,7 +400,9 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
     const int ostep = gridDim.x;
 
     auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
-        return reinterpret_cast<const char *>(a.x + m * a.x_stride + c * a.x_slot_stride);
+        const int c0 = c * CBC * 8;
+        return reinterpret_cast<const char *>(a.x + m * a.x_stride + (c0 >> 7) * a.x_slot_stride) +
+               (long long)((c0 & 127) >> 3) * v * 16;
     };
 
     u32x4 sreg[S::N];
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
             auto hook = [&](int s) __attribute__((always_inline)) {
                 stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
             };
-            mfma16_core<RT, 2, NST, AD>(acc, xs, cur, v,
+            mfma16_core<RT, 2, NST, AD, 2>(acc, xs, cur, v,
                                         reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * 512 + o0) * 16,
                                         wlane, wts_b, wts_b, 2 * wbs_b, 1, 1, r, h, hook);
             __syncthreads();
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
             *reinterpret_cast<h4 *>(d + G::PLANE) = lo;
         }
         __syncthreads();
-        mfma16_core<RT, 1, 4, 4>(acc, xs, 0, v,
+        mfma16_core<RT, 1, 4, 4, 4>(acc, xs, 0, v,
                                  reinterpret_cast<const char *>(a.w) + ((long long)(c0 >> 3) * a.cout + o0) * 16,
                                  wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
     }
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
             *reinterpret_cast<h8 *>(xs + GD::PLANE + (blk * GD::VP + vi) * 16) = lo;
         }
         __syncthreads();
-        mfma16_core<RT, 1, 2, 2>(acc, xs, 0, v,
+        mfma16_core<RT, 1, 2, 2, 2>(acc, xs, 0, v,
                                  reinterpret_cast<const char *>(a.w) + ((long long)(g.c >> 3) * a.cout + o0) * 16,
                                  wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
     }
@@ -724,7 +726,7 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
     DANCE_REQUIRE(v <= 128);        // larger rings: unfused dance_conv16 sequence (accumulators)
     const int rt = v <= 64 ? 2 : 4;
-    const size_t lds = (size_t)2 * 2 * 16 * (rt * 32 + 1) * 16;    // two 128-channel chunk images
+    const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // two 64-channel chunk images
     const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
     dim3 grid(slots > 0 && slots < n ? slots : n);
     int rc = 0;

@@ -1,1 +1,1 @@
-KB_ALL=1 timeout -k 10 60 python tools/kbench16.py 128 256 512 1024 2>&1 | grep -v amdgpu.ids
+DANCE_DEBUG_STAMPS=1 timeout -k 10 60 python tools/kbench16.py 2 1600 2>&1 | grep -v amdgpu.ids

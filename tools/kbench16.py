@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 from dance_amd import ops
 from dance_amd._lib import lib, check, ptr, current_stream
 dev = torch.device('cuda')
-def run(n, v, cin, cout, taps, dil, reps=3 if int(os.environ.get('DANCE_DEBUG_FLAGS', '0')) & 64 else 20, residual=True, tag=""):
+def run(n, v, cin, cout, taps, dil, reps=3 if os.environ.get('DANCE_DEBUG_STAMPS') else 20, residual=True, tag=""):
     x = ops.to_p16(torch.randn((n, cin, v), device=dev))
     w, s = ops.pack_conv_weight16(torch.randn((cout, cin, taps), device=dev) * 0.03)
     b = (torch.randn((cout,), device=dev) * s).contiguous()
