@@ -9,6 +9,7 @@ Every arithmetic step runs in libdance_hip.so (see include/dance_hip.h); this fi
 re-lays-out parameters once and enqueues `dance_snake_evolve` per iteration.
 """
 import ctypes
+import os
 
 import torch
 
@@ -145,9 +146,11 @@ class ContourDeformer:
     MAX_CHUNK = 4096      # contours per kernel sequence: bounds the workspace
 
     def __init__(self, nets, padding="reflection", de_loc_type="derange", individual_scale=True,
-                 attention=True, fused_head=True, precision="fp16x3"):
+                 attention=True, fused_head=True, precision=None):
         """precision: "fp16x3" -- split-half operands, three f16 MFMAs per product, fp32
         accumulation (fp32-level accuracy, the default); "fp32" -- exact fp32 MFMA."""
+        if precision is None:
+            precision = os.environ.get("DANCE_PRECISION", "fp16x3")
         if precision not in ("fp16x3", "fp32"):
             raise ValueError("precision must be 'fp16x3' or 'fp32'")
         self.precision = precision
