@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libdance_hip.so")
+# DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
+SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
 ABI_VERSION = 1
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
