@@ -304,6 +304,40 @@ extern "C" int dance_roll_array(const float *array, const int64_t *step, float *
 }
 
 // ------------------------------------------------------------------------------------
+// contour_upsample_2x (snake_head.py:1752-1761): out[2i] = p[i], out[2i+1] = (p[i] + p[i+1 mod V]) / 2
+// (one fp32 add, one exact halving -- this file is compiled with contraction off)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_contour_upsample_2x(const float *__restrict__ loc,
+                                                             float *__restrict__ out, long long total, int v)
+{
+    const long long t = blockIdx.x * 256ll + threadIdx.x;       // one output coordinate pair
+    if (t >= total)
+        return;
+    const long long nn = t / (2 * v);
+    const int j = (int)(t - nn * 2 * v), i = j >> 1;
+    const float2 a = reinterpret_cast<const float2 *>(loc)[nn * v + i];
+    float2 o = a;
+    if (j & 1) {
+        const float2 b = reinterpret_cast<const float2 *>(loc)[nn * v + (i + 1 == v ? 0 : i + 1)];
+        o.x = (a.x + b.x) / 2.0f;
+        o.y = (a.y + b.y) / 2.0f;
+    }
+    reinterpret_cast<float2 *>(out)[t] = o;
+}
+
+extern "C" int dance_contour_upsample_2x(const float *loc, float *out, int n, int v, void *stream)
+{
+    DANCE_REQUIRE(n >= 0 && v >= 1);
+    const long long total = 2ll * n * v;
+    if (total == 0)
+        return 0;
+    DANCE_REQUIRE(loc && out && total < (1ll << 38));
+    hipLaunchKernelGGL(k_contour_upsample_2x, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, loc, out, total, v);
+    return launch_check(__func__);
+}
+
+// ------------------------------------------------------------------------------------
 // Fused resampler (snake_head.py:764-794 + utils.cu:215-331 + the polygon builders):
 // one wavefront per polygon.  Lanes build the polygon and its edge lengths in LDS; lane 0
 // runs the short serial part (left-to-right length sum, round-half-even counts, stable

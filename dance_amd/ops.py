@@ -67,6 +67,17 @@ def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True):
 
 
 # ------------------------------------------------------------------------------ layout
+def contour_upsample_2x(locations):
+    """`RefineNet.contour_upsample_2x` (snake_head.py:1752-1761): (N,V,2) -> (N,2V,2)."""
+    _need_gpu(locations)
+    loc = locations.contiguous().float()
+    n, v, _ = loc.shape
+    out = torch.empty((n, 2 * v, 2), dtype=torch.float32, device=loc.device)
+    with torch.cuda.device(loc.device):
+        check(lib().dance_contour_upsample_2x(ptr(loc), ptr(out), n, v, current_stream()), "contour_upsample_2x")
+    return out
+
+
 def nchw_to_nhwc(features, att_channels):
     """(B, att+C, Hf, Wf) NCHW -> ((B,Hf,Wf,C) NHWC, (B,Hf,Wf) attention plane or None)."""
     _need_gpu(features)

@@ -57,6 +57,11 @@ int dance_calculate_wnp(const int64_t *edge_num, const int64_t *edge_start_idx,
 int dance_roll_array(const float *array, const int64_t *step, float *new_array, int b,
                      int n, int d, void *stream);
 
+/* reference: snake_head.py:1752-1761 (`RefineNet.contour_upsample_2x`, used only with
+ * LAST_UP_SAMPLE).  loc (n,v,2) f32 -> out (n,2v,2): even slots copy, odd slots are the
+ * mid-points (p[i] + p[i+1 mod v]) / 2, rounded as the reference's add-then-divide. */
+int dance_contour_upsample_2x(const float *loc, float *out, int n, int v, void *stream);
+
 /* ------------------------------------------------- contour initialisation (a11-a15) - */
 enum {
     DANCE_POLY_RAW = 0,      /* src = polygons (n,e,2)                                  */

@@ -339,6 +339,18 @@ def gen_dsnake(dh):
           checksum=ck, feat_seed=701, weight_seed=WEIGHT_SEED, hf=hf, wf=wf, smooth=1)
 
 
+def gen_upsample2x(sh):
+    """`RefineNet.contour_upsample_2x` (snake_head.py:1752-1761) on seeded contours."""
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    for i, (n, v) in enumerate([(1, 3), (5, 128), (3, 37)]):
+        loc = torch.rand((n, v, 2), generator=g) * 1200.0 - 100.0
+        ref = sh.RefineNet.contour_upsample_2x(loc)
+        assert torch.equal(snake_ref.contour_upsample_2x(loc), ref)
+        out["loc%d" % i], out["out%d" % i] = loc, ref
+    _save("g7_upsample2x", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -351,6 +363,7 @@ def main():
     gen_snakenet(sh)
     gen_dance(sh)
     gen_dsnake(dh)
+    gen_upsample2x(sh)
     print("golden vectors written to", os.path.normpath(OUT))
 
 

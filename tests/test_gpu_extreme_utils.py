@@ -139,3 +139,13 @@ def test_fused_resampler_builders_and_large(device):
     # E > p_num cannot be satisfied: flagged instead of the reference's out-of-bounds walk
     with pytest.raises(AssertionError):
         ops.uniform_upsample(torch.rand((2, 12, 2)).to(device), 5)
+
+
+def test_contour_upsample_2x_golden_bit_exact(device):
+    g = golden("g7_upsample2x")
+    for i in range(3):
+        got = ops.contour_upsample_2x(g["loc%d" % i].to(device))
+        assert torch.equal(got.cpu(), g["out%d" % i])
+    big = torch.rand((3000, 128, 2)) * 1000
+    from oracle import snake_ref
+    assert torch.equal(ops.contour_upsample_2x(big.to(device)).cpu(), snake_ref.contour_upsample_2x(big))

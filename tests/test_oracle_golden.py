@@ -114,6 +114,12 @@ def test_dsnake_restatement():
         assert rel_err(out["preds"][i], g["pred%d" % i]) < 1e-5
 
 
+def test_upsample2x_restatement():
+    g = golden("g7_upsample2x")
+    for i in range(3):
+        assert torch.equal(snake_ref.contour_upsample_2x(g["loc%d" % i]), g["out%d" % i])
+
+
 def test_extreme_utils_known_answers():
     # 5x5 map, one box, hand-computed: votes all point at the centre (2,2)
     h = w = 5
