@@ -153,6 +153,86 @@ __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *
 #undef DANCE_LOAD_B
 }
 
+// The same contraction on v_mfma_f32_16x16x32_f16 (K = 32 channels = 4 channel blocks per
+// MFMA, 16 x 16 output tiles): the chip holds a higher clock on this shape under load
+// (MI355X_MICROARCH.md, DVFS give-back item 7).  A wave's 32 x (RT * 32) output is 2 row tiles
+// x 2 RT column tiles of 4 accumulator registers.
+//   lane = (q4 = lane >> 4, c16 = lane & 15):  A word W[o0 + 16 i + c16][block 4 s + q4],
+//   B word X[block 4 s + q4][vertex 16 j + c16],  C/D: vertex 16 j + c16, channels 4 q4 .. + 3.
+// NST = steps of 32 channels per chunk; wlane = (q4 * cout + c16) * 16; wstep_b = 4 blocks.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int RT, int NST, int AD, int NB, typename Hook>
+__device__ __forceinline__ void mfma16_core_s(f32x4 (&acc)[2][2 * RT], const char *xs, unsigned lds0, int v,
+                                              const char *wchunk, unsigned wlane, long long wps_b,
+                                              long long wts_b, long long wstep_b, int taps, int dilation,
+                                              int c16, int q4, Hook hook)
+{
+    constexpr int CT = 2 * RT, NT = NST * CT, DB = NB - 1, D = AD - 1;
+    static_assert(NST % AD == 0 && D <= NST && D >= 1, "weight buffer rotation must close over a tap");
+    static_assert(NT % NB == 0 && DB <= NT - CT && DB >= 1, "tile buffer rotation must close over a tap");
+    using G = Geo<RT, 4 * NST>;
+    constexpr int SSTEP = 4 * G::VP * 16;
+    const unsigned rowb = lds0 + q4 * G::VP * 16;
+    const unsigned lim = rowb + v * 16, d16 = dilation * 16, v16 = v * 16;
+    unsigned p[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+        p[j] = rowb + ring16(j * 16 + c16, -(taps >> 1) * dilation, v) * 16;
+
+    h8 ah[AD][2], al[AD][2];
+#define DANCE_LOAD_A(SLOT, PTR)                                                                   \
+    do {                                                                                          \
+        const char *pa_ = (PTR);                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                        \
+            ah[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wlane + i_ * 256);                 \
+            al[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + i_ * 256);         \
+        }                                                                                         \
+    } while (0)
+#define DANCE_LOAD_B(Q)                                                                           \
+    do {                                                                                          \
+        constexpr int q_ = (Q) % NT, s_ = q_ / CT, j_ = q_ % CT;                                  \
+        bh[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[j_] + s_ * SSTEP);                    \
+        bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[j_] + s_ * SSTEP + G::PLANE);         \
+        if (s_ == NST - 1) {                                                                      \
+            const unsigned tpos_ = p[j_] + d16;                                                   \
+            p[j_] = tpos_ >= lim ? tpos_ - v16 : tpos_;                                           \
+        }                                                                                         \
+    } while (0)
+#pragma unroll
+    for (int q = 0; q < D; ++q)
+        DANCE_LOAD_A(q, wchunk + q * wstep_b);
+    h8 bh[NB], bl[NB];
+    dance::static_for<0, DB>([&](auto q) __attribute__((always_inline)) { DANCE_LOAD_B(decltype(q)::value); });
+
+    const char *wtap = wchunk;
+    for (int tap = 0; tap < taps; ++tap) {
+        const bool more = tap + 1 < taps;
+        dance::static_for<0, NT>([&](auto qq) __attribute__((always_inline)) {
+            constexpr int q = decltype(qq)::value, s = q / CT, j = q % CT;
+            if constexpr (j == 0) {
+                if (s + D < NST)
+                    DANCE_LOAD_A((s + D) % AD, wtap + (s + D) * wstep_b);
+                else if (more)
+                    DANCE_LOAD_A((s + D) % AD, wtap + wts_b + (s + D - NST) * wstep_b);
+                if (tap == 0)
+                    hook(s);
+            }
+            DANCE_LOAD_B(q + DB);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][0], bh[q % NB], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][1], bh[q % NB], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][0], bl[q % NB], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][1], bl[q % NB], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][0], bh[q % NB], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][1], bh[q % NB], acc[1][j], 0, 0, 0);
+        });
+        wtap += wts_b;
+    }
+#undef DANCE_LOAD_A
+#undef DANCE_LOAD_B
+}
+
 // Staging of the next chunk image: this wave's rows (wave, wave + NW, ...), lanes along the
 // row; lanes past the ring length repeat the last vertex (same value to the same address),
 // which keeps loads and stores branch-free and the staging array in registers.
@@ -351,6 +431,161 @@ __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
                             for (int s = 16; s >= 1; s >>= 1)
                                 m = dance::nan_max(__shfl_xor(m, s, 64), m);
                             if (re == 0)
+                                a.yf[nn * a.cout + ob + i] = m;
+                        }
+                    }
+                }
+            }
+            __syncthreads();                    // every wave is done with chunk k (and the residual)
+            if (has_next)
+                stage_commit<RT, CBC, NW>(sreg, xs, nxt, v, wave, lane);
+            __syncthreads();
+        }
+    }
+}
+
+// k_conv16 on 16x16x32 MFMAs (V <= 128).  4 waves, one 32-channel tile each (128 outputs per
+// workgroup, grid.y tiles of 128); chunks of 64 (V <= 128) or 32 channels double-buffered in
+// LDS: while chunk k is multiplied, chunk k+1 -- of this contour or, when the grid is smaller
+// than n, of the workgroup's next contour -- is staged into registers and committed to the
+// other buffer at the chunk boundary.  With two chunks per contour (128 channels) both stay
+// resident, and the residual is read back from LDS in the epilogue.
+template <int RT>
+__global__ __launch_bounds__(256, 2) void k_conv16s(Conv16Args a, int n)
+{
+    static_assert(RT <= 4, "larger rings use k_conv16");
+    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NW = 4, NB = 4, CT = 2 * RT;
+    using G = Geo<RT, CBC>;
+    using S = StageGeo<RT, CBC, NW>;
+    extern __shared__ __attribute__((aligned(16))) char xs[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int o0 = blockIdx.y * 128 + wave * 32;
+    const bool active = o0 < a.cout;
+    const int v = a.v;
+    const long long wbs_b = (long long)a.cout * 16, wts_b = (long long)(a.cin >> 3) * wbs_b,
+                    wps_b = (long long)a.taps * wts_b;
+    const unsigned wlane = (unsigned)(q4 * a.cout + c16) * 16u;
+    const int nch = a.cin / (CBC * 8);
+    const bool res_lds = a.residual && nch <= 2;
+    const int ostep = gridDim.x;
+
+    // byte pointer to (plane 0, first block) of chunk c of contour m
+    auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
+        const int c0 = c * CBC * 8;
+        return reinterpret_cast<const char *>(a.x + m * a.x_stride + (c0 >> 7) * a.x_slot_stride) +
+               (long long)((c0 & 127) >> 3) * v * 16;
+    };
+
+    u32x4 sreg[S::N];
+    long long nn = blockIdx.x;
+    stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane);
+    stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
+    __syncthreads();
+
+    int k = 0;
+    for (; nn < n; nn += ostep) {
+        f32x4 acc[2][CT];
+        if (active) {
+            // accumulators carry 2^s-scaled sums; a per-contour row start is scaled to match
+            const float *bsrc = a.rowinit ? a.rowinit + nn * a.cout : a.bias_s;
+            const float mul = a.rowinit ? 1.0f / a.winv : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(bsrc + o0 + 16 * i + 4 * q4);
+                const f32x4 bv = {b4.x * mul, b4.y * mul, b4.z * mul, b4.w * mul};
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[i][j] = bv;
+            }
+        }
+        for (int c = 0; c < nch; ++c, ++k) {
+            const unsigned cur = (k & 1) * G::BYTES, nxt = ((k + 1) & 1) * G::BYTES;
+            const bool last = c + 1 == nch;
+            const bool has_next = !last || nn + ostep < n;
+            // nothing left to stage: re-read the current chunk (valid memory), never committed
+            const char *ssrc = has_next ? chunk_src(last ? nn + ostep : nn, last ? 0 : c + 1) : chunk_src(nn, c);
+            if (active) {
+                auto hook = [&](int s) __attribute__((always_inline)) {
+                    stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
+                };
+                mfma16_core_s<RT, NST, AD, NB>(acc, xs, cur, v,
+                                               reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * a.cout + o0) * 16,
+                                               wlane, wps_b, wts_b, 4 * wbs_b, a.taps, a.dilation, c16, q4, hook);
+            } else {
+                stage_load<RT, CBC, NW>(sreg, 0, S::N, ssrc, v, wave, lane);
+            }
+            if (last && active) {
+                // epilogue: lane = vertex column 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3.
+                // (ce, qe) are made opaque so that the compiler does not hoist the epilogue's
+                // addresses and per-channel constants above the MFMA chunks.
+                int ce = c16, qe = q4;
+                asm volatile("" : "+v"(ce), "+v"(qe));
+                _Float16 *yslot = a.y ? a.y + nn * a.y_stride + (o0 >> 7) * a.y_slot_stride : nullptr;
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int ob = o0 + 16 * i2 + 4 * qe;
+                    float4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+                    if (a.scale) {
+                        sc4 = *reinterpret_cast<const float4 *>(a.scale + ob);
+                        sh4 = *reinterpret_cast<const float4 *>(a.shift + ob);
+                    }
+                    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+                    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    // residual source: input row (ob / 8), half (ob / 4) & 1: LDS image or global
+                    const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
+                    const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
+                    const unsigned rbuf = ((k - (nch - 1) + xchunk) & 1) * G::BYTES;
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) {
+                        const int vv = j * 16 + ce;
+                        if (vv >= v)
+                            continue;
+                        float val[4];
+                        h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};
+                        if (a.residual) {
+                            if (res_lds) {
+                                const char *q = xs + rbuf + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
+                                rh = *reinterpret_cast<const h4 *>(q);
+                                rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
+                            } else {
+                                const _Float16 *q = a.x + nn * a.x_stride + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
+                                rh = *reinterpret_cast<const h4 *>(q);
+                                rl = *reinterpret_cast<const h4 *>(q + 128ll * v);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float x = acc[i2][j][i] * a.winv;
+                            if (a.relu)
+                                x = relu_nan(x);
+                            if (a.scale)
+                                x = x * sc[i] + sh[i];
+                            if (a.residual)
+                                x += (float)rh[i] + (float)rl[i];
+                            val[i] = x;
+                        }
+                        if (a.maxv) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                mx[i] = dance::nan_max(val[i], mx[i]);
+                        } else if (yslot) {
+                            dance::store_p16(yslot, v, (ob & 127) >> 3, vv, xhalf, val);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                a.yf[nn * a.yf_stride + (long long)(ob + i) * v + vv] = val[i];
+                        }
+                    }
+                    if (a.maxv) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float m = mx[i];
+#pragma unroll
+                            for (int s = 8; s >= 1; s >>= 1)
+                                m = dance::nan_max(__shfl_xor(m, s, 64), m);
+                            if (ce == 0)
                                 a.yf[nn * a.cout + ob + i] = m;
                         }
                     }
@@ -707,6 +942,24 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
     // makes workgroups persistent over contours nn, nn + grid, ... (tuning knob)
     const int slots = env_int("DANCE_CONV16_SLOTS", 0);
     dim3 grid(slots > 0 && slots < n ? slots : n, dance::ceil_div(cout, 128));
+    // 16x16x32 tiles by default for V <= 128 (measured 2-5 % faster at equal MFMA cycles: the
+    // chip holds a higher clock on that shape); DANCE_MFMA_SHAPE=32 selects the 32x32x16 kernel
+    static const int shape16 = env_int("DANCE_MFMA_SHAPE", 16) == 16;
+    if (shape16 && rt <= 4) {
+        int rc = 0;
+        if (rt == 2) {
+            rc = big_lds(k_conv16s<2>, lds, __func__);
+            if (!rc)
+                hipLaunchKernelGGL(k_conv16s<2>, grid, dim3(256), lds, (hipStream_t)stream, a, n);
+        } else {
+            rc = big_lds(k_conv16s<4>, lds, __func__);
+            if (!rc)
+                hipLaunchKernelGGL(k_conv16s<4>, grid, dim3(256), lds, (hipStream_t)stream, a, n);
+        }
+        if (rc)
+            return rc;
+        return launch_check(__func__);
+    }
     LAUNCH_RT(k_conv16, rt, grid, dim3(256), lds, (hipStream_t)stream, "dance_conv16", a, n);
     return launch_check(__func__);
 }

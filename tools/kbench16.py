@@ -5,7 +5,7 @@ from dance_amd import ops
 from dance_amd._lib import lib, check, ptr, current_stream
 dev = torch.device('cuda')
 def run(n, v, cin, cout, taps, dil, reps=3 if os.environ.get('DANCE_DEBUG_STAMPS') else 20, residual=True, tag=""):
-    x = ops.to_p16(torch.randn((n, cin, v), device=dev))
+    x = ops.to_p16(torch.randn((n, cin, v), device=dev) * (0.0 if os.environ.get('KB_ZERO') else 1.0))
     w, s = ops.pack_conv_weight16(torch.randn((cout, cin, taps), device=dev) * 0.03)
     b = (torch.randn((cout,), device=dev) * s).contiguous()
     sc = torch.rand((cout,), device=dev) + 0.5
