@@ -1,0 +1,118 @@
+"""GPU: BASELINE.json configs 3, 4 and 5 at their FULL sizes, checked through properties that
+do not need a full-size CPU run: a random sample of contours is recomputed by the oracle on
+just its own image (every contour depends only on its image's features -- SURVEY 8e), results
+are independent of the chunking over contours, and permuting the contours permutes the
+output.  Per-iteration tolerance 1e-4 norm-wise (iteration 0 from identical inputs; later
+iterations are compared on the oracle's own chain for the sampled contours, on band-limited
+features where the chain is well conditioned)."""
+import pytest
+import torch
+
+from _util import REL_TOL, FakeBoxes, FakeInstances, coord_rel_err, dance_state_dict, dsnake_state_dict
+from dance_amd import modules, ops, snake, synthetic
+from oracle import snake_ref
+
+pytestmark = pytest.mark.gpu
+HF, WF = 200, 304
+
+
+def _features(b, c, seed, device, attention=True):
+    """(b, [1+]c, HF, WF) band-limited features, generated image by image on the host."""
+    out = torch.empty((b, c + (1 if attention else 0), HF, WF), dtype=torch.float32, device=device)
+    # 8 distinct maps, cycled: bounds host time, every image still differs from its neighbours
+    maps = [synthetic.make_smooth_features(1, c, HF, WF, seed + k, attention=attention)[0].to(device)
+            for k in range(min(b, 8))]
+    for i in range(b):
+        out[i] = maps[i % 8]
+    return out
+
+
+def _dance_inputs(b, per, v, seed, device):
+    n = b * per
+    boxes = synthetic.make_boxes(n, HF * 4, WF * 4, seed)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
+    init, _ = ops.uniform_upsample(boxes.to(device), v, kind=ops.POLY_BOX)
+    idx = torch.arange(b).repeat_interleave(per).float()
+    return boxes, whs, init, idx
+
+
+def _check_sample(preds, sd, feats, init, idx, whs, sample):
+    """oracle on the sampled contours, each with its own image only"""
+    for j in sample:
+        img = int(idx[j])
+        f1 = feats[img:img + 1].cpu()
+        want = snake_ref.dance_deform(sd, f1, init[j:j + 1].cpu(), torch.zeros(1), [(HF * 4, WF * 4)],
+                                      whs[j:j + 1].cpu())
+        for it in range(3):
+            assert coord_rel_err(preds[it][j:j + 1], want[it]) < REL_TOL, (j, it)
+
+
+def test_config3_dance_32x100_attention(device):
+    """BASELINE config 3: batch 32 images x 100 instances, attentive deformation, all iterations."""
+    b, per, v = 32, 100, 128
+    cfg, sd, _ = dance_state_dict(1234, v)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    feats = _features(b, 256, 500, device)
+    boxes, whs, init, idx = _dance_inputs(b, per, v, 77, device)
+    d = snake.ContourDeformer(nets)
+    preds = d.deform(feats, init, idx.to(device), [(HF * 4, WF * 4)] * b, whs.to(device))
+    assert all(p.shape == (b * per, v, 2) and bool(torch.isfinite(p).all()) for p in preds)
+    # chunk invariance (bit-exact) and permutation equivariance (bit-exact)
+    d2 = snake.ContourDeformer(nets)
+    d2.MAX_CHUNK = 1000
+    again = d2.deform(feats, init, idx.to(device), [(HF * 4, WF * 4)] * b, whs.to(device))
+    perm = torch.randperm(b * per, generator=torch.Generator().manual_seed(3)).to(device)
+    shuffled = d.deform(feats, init[perm], idx.to(device)[perm], [(HF * 4, WF * 4)] * b, whs.to(device)[perm])
+    for it in range(3):
+        assert torch.equal(preds[it], again[it])
+        assert torch.equal(preds[it][perm], shuffled[it])
+    _check_sample(preds, sd, feats, init, idx, whs, [0, 1234, 3199])
+
+
+def test_config4_dsnake_32x100(device):
+    """BASELINE config 4: Dsnake R50, batch 32 images x 100 instances: init (V=40) ->
+    extreme points -> octagon -> 3 evolves, through the drop-in module."""
+    b, per = 32, 100
+    cfg, sd, _ = dsnake_state_dict(1234)
+    head = modules.DsnakeHead(cfg)
+    head.load_state_dict(sd)
+    head = head.to(device).eval()
+    feats = _features(b, 256, 900, device, attention=False)
+    boxes = synthetic.make_boxes(b * per, HF * 4, WF * 4, 78).view(b, per, 4)
+    insts = [FakeInstances((HF * 4, WF * 4), pred_boxes=FakeBoxes(boxes[i].to(device))) for i in range(b)]
+    with torch.no_grad():
+        res, _ = head(feats, insts, None)
+    got = torch.stack([r.pred_polys.tensor for r in res])             # (b, per, 128, 2)
+    assert got.shape == (b, per, 128, 2) and bool(torch.isfinite(got).all())
+    # independence: two images alone give the same contours as inside the batch of 32
+    for i in (0, 31):
+        alone = [FakeInstances((HF * 4, WF * 4), pred_boxes=FakeBoxes(boxes[i].to(device)))]
+        with torch.no_grad():
+            r1, _ = head(feats[i:i + 1], alone, None)
+        assert torch.equal(r1[0].pred_polys.tensor, got[i])
+    # oracle on a sample of instances of one image (its own feature map only)
+    sample = [0, 50, 99]
+    want = snake_ref.dsnake_deform(sd, feats[5:6].cpu(), [boxes[5][sample]])
+    assert coord_rel_err(got[5][sample], want["preds"][-1]) < REL_TOL
+
+
+def test_config5_large_sweep_256v(device):
+    """BASELINE config 5, one GPU's view of the sweep at FULL size: 256 images x 300 instances
+    x 256 vertices (76,800 contours; 16 GB of features), chunked over contours."""
+    b, per, v = 256, 300, 256
+    cfg, sd, _ = dance_state_dict(1234, v)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    feats = _features(b, 256, 1300, device)
+    boxes, whs, init, idx = _dance_inputs(b, per, v, 79, device)
+    d = snake.ContourDeformer(nets)
+    f = d.prepare_features(feats)
+    preds = d.deform(f, init, idx.to(device), [(HF * 4, WF * 4)] * b, whs.to(device), layout="nhwc")
+    assert all(p.shape == (b * per, v, 2) and bool(torch.isfinite(p).all()) for p in preds)
+    # the first and the last image's contours, recomputed alone, are bit-identical
+    for img in (0, b - 1):
+        sl = slice(img * per, (img + 1) * per)
+        alone = d.deform(feats[img:img + 1], init[sl], torch.zeros(per, device=device), [(HF * 4, WF * 4)],
+                         whs[sl].to(device))
+        for it in range(3):
+            assert torch.equal(alone[it], preds[it][sl]), (img, it)
+    _check_sample(preds, sd, feats, init, idx, whs, [7, 40000, 76799])
