@@ -52,7 +52,8 @@ def parse():
                     help="fp16x3 (default): split-half operands, 3 f16 MFMAs per product, fp32 "
                          "accumulate (fp32-level accuracy); fp32: exact-fp32 MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=40,
+                    help="timed oracle runs of config 1 (about 10 s of CPU work in total)")
     return ap.parse_args()
 
 

@@ -940,7 +940,7 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
     const size_t lds = (size_t)2 * 2 * cbc * (rt * 32 + 1) * 16;   // two chunk images
     // one workgroup per contour by default (the dispatcher balances them); a smaller grid
     // makes workgroups persistent over contours nn, nn + grid, ... (tuning knob)
-    const int slots = env_int("DANCE_CONV16_SLOTS", 0);
+    static const int slots = env_int("DANCE_CONV16_SLOTS", 0);
     dim3 grid(slots > 0 && slots < n ? slots : n, dance::ceil_div(cout, 128));
     // 16x16x32 tiles by default for V <= 128 (measured 2-5 % faster at equal MFMA cycles: the
     // chip holds a higher clock on that shape); DANCE_MFMA_SHAPE=32 selects the 32x32x16 kernel
@@ -980,7 +980,7 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     DANCE_REQUIRE(v <= 128);        // larger rings: unfused dance_conv16 sequence (accumulators)
     const int rt = v <= 64 ? 2 : 4;
     const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // two 64-channel chunk images
-    const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
+    static const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
     dim3 grid(slots > 0 && slots < n ? slots : n);
     int rc = 0;
     if (rt == 2) {
