@@ -166,6 +166,23 @@ def main():
         elapsed = float(t.item())
     assert out.shape == (world * n, v, 2) and bool(torch.isfinite(out).all())
 
+    # the gather stage on its own (k_gather: 4 taps x 257 channels per vertex -> (N, 258, V)),
+    # outside the timed region: the HBM-bound form of the stage that k_gather_head* fuses
+    gather_alone_ms = None
+    if rank == 0:
+        f_nhwc, att_plane = deformer.prepare_features(feats) if pre is None else pre
+        idx32 = image_idx.to(torch.int32)
+        for _ in range(2):
+            ops.gather_features(f_nhwc, att_plane, init, idx32, ops.PAD_REFLECTION, "derange")
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for _ in range(10):
+            ops.gather_features(f_nhwc, att_plane, init, idx32, ops.PAD_REFLECTION, "derange")
+        g1.record()
+        torch.cuda.synchronize()
+        gather_alone_ms = g0.elapsed_time(g1) / 10
+        del f_nhwc, att_plane
+
     if rank == 0:
         # per-stage device time from the HIP events recorded inside the timed steps
         stage_ms = [0.0] * len(STAGE_NAMES)
@@ -222,7 +239,12 @@ def main():
                        "algorithmic_GBps": gather_gbps, "frac_of_hbm_peak": gather_gbps / PEAK_HBM_GBPS,
                        "avg_launch_ms": head_ms,
                        "note": "the fused kernel is MFMA-bound (85 MFLOP per 526 KB gathered per "
-                               "contour-iteration), not HBM-bound"},
+                               "contour-iteration), not HBM-bound",
+                       "standalone_kernel": "k_gather (gather + de_location + concat only, untimed extra)",
+                       "standalone_ms": gather_alone_ms,
+                       "standalone_algorithmic_GBps": GATHER_BYTES_PER_VERTEX * v * n / (gather_alone_ms * 1e-3) / 1e9,
+                       "standalone_frac_of_hbm_peak": GATHER_BYTES_PER_VERTEX * v * n / (gather_alone_ms * 1e-3) / 1e9
+                                                      / PEAK_HBM_GBPS},
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms),
         }
