@@ -182,6 +182,16 @@ def main():
         torch.cuda.synchronize()
         gather_alone_ms = g0.elapsed_time(g1) / 10
         del f_nhwc, att_plane
+        # the reference's `contour_sampling` scope (snake_head.py:1786): boxes -> V-point contours
+        bdev = boxes.to(dev)
+        for _ in range(2):
+            ops.uniform_upsample(bdev, v, kind=ops.POLY_BOX)
+        g0.record()
+        for _ in range(10):
+            ops.uniform_upsample(bdev, v, kind=ops.POLY_BOX)
+        g1.record()
+        torch.cuda.synchronize()
+        sampling_ms = g0.elapsed_time(g1) / 10
 
     if rank == 0:
         # per-stage device time from the HIP events recorded inside the timed steps
@@ -247,6 +257,9 @@ def main():
                                                       / PEAK_HBM_GBPS},
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms),
+            "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,
+                                 "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),
+                                 "note": "reference scope `contour_sampling`, outside the timed step"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_reps)
