@@ -25,6 +25,7 @@ SOURCES = [
     ("gather.hip", []),
     ("snake_mfma.hip", []),
     ("snake16.hip", []),
+    ("featprep16.hip", []),
 ]
 HEADERS = ["common.h", "sampling.h", "p16.h", os.path.join("..", "..", "include", "dance_hip.h")]
 

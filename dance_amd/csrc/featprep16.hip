@@ -1,0 +1,353 @@
+// featprep16.hip -- SURVEY 8f row 1, the step right before the contour path:
+// RefineNet.bottom_out = NUM_CONVS x [Conv2d 3x3 (C -> C, pad 1, no bias) -> GroupNorm(32) -> ReLU]
+// on the stride-4 feature map (snake_head.py:562-615, used 1816-1820), ending directly in the
+// NHWC fp32 layout the gather kernels read (no separate layout pass).
+//
+// Same arithmetic as snake16.hip: split-half fp16 operands, three f16 MFMAs per product,
+// fp32 accumulation (fp32-level accuracy at the 16-bit matrix rate).
+//
+//   k_nchw_to_p16img : NCHW fp32 -> "P16 image" [b][plane hi/lo][c/8][y][x][8] fp16
+//   k_conv3x3_16     : implicit GEMM, one workgroup = 2 rows x 64 pixels x 128 output channels
+//                      (4 waves x 32 channels, 16x16x32 MFMA tiles).  Input chunks of 32
+//                      channels with their 1-pixel halo (4 rows x 66 pixels) are double-buffered
+//                      in LDS; the 9 taps are immediate offsets into that image.  Output: the
+//                      raw convolution, fp32, channel-blocked [b][c/16][y][x][16] (every wave
+//                      store is 1 KB contiguous), plus per-(image, group) sum / sum of squares
+//                      (fp64 atomics) for the GroupNorm that follows.
+//   k_gn_relu        : GroupNorm + ReLU from those statistics, written either as the next
+//                      convolution's P16 image or as the final NHWC fp32 feature map.
+#include "common.h"
+#include "p16.h"
+
+using dance::launch_check;
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------- layout in
+__global__ __launch_bounds__(256) void k_nchw_to_p16img(const float *__restrict__ src, int c_total, int c_off,
+                                                        _Float16 *__restrict__ dst, int c, long long hw)
+{
+    // grid: (ceil(hw / 256), c / 8, b); thread = one pixel of one 8-channel block
+    const long long p = blockIdx.x * 256ll + threadIdx.x;
+    if (p >= hw)
+        return;
+    const int cb = blockIdx.y, b = blockIdx.z, cbt = c >> 3;
+    const float *s = src + ((long long)b * c_total + c_off + cb * 8) * hw + p;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 x, y;
+        dance::split_half(s[j * hw], x, y);
+        hi[j] = x;
+        lo[j] = y;
+    }
+    _Float16 *d = dst + (((long long)b * 2 * cbt + cb) * hw + p) * 8;
+    *reinterpret_cast<h8 *>(d) = hi;
+    *reinterpret_cast<h8 *>(d + (long long)cbt * hw * 8) = lo;
+}
+
+// ---------------------------------------------------------------------------- conv 3x3
+struct Conv2dArgs {
+    const _Float16 *x;      // P16 image
+    const h8 *w;            // [plane][tap ky*3+kx][cin/8][cout] words (ops.pack_conv_weight16)
+    float winv;             // 2^-s of the weight scaling
+    float *y;               // [b][cout/16][h][w][16] fp32, raw convolution
+    double *stats;          // [b][cout/group_ch][2] sum, sum of squares (zeroed by the host entry)
+    int h, w_, cin, cout, group_ch;
+};
+
+constexpr int C2_HR = 4, C2_PW = 66, C2_CB = 4;
+constexpr int C2_PLANE = C2_CB * C2_HR * C2_PW * 16;        // bytes per plane of a chunk image
+constexpr int C2_BYTES = 2 * C2_PLANE;                      // 33,792
+constexpr int C2_WORDS = C2_BYTES / 16;                     // 2112
+constexpr int C2_NSTG = 9;                                  // staged 16-B loads per thread and chunk
+
+__global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char xs[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int tiles_x = (a.w_ + 63) >> 6, rows2 = (a.h + 1) >> 1;
+    const int bid = blockIdx.x;
+    const int tx = bid % tiles_x, ty = (bid / tiles_x) % rows2, b = bid / (tiles_x * rows2);
+    const int x0 = tx * 64, y0 = ty * 2;
+    const int o0 = blockIdx.y * 128 + wave * 32;
+    const long long hw = (long long)a.h * a.w_;
+    const int cbt = a.cin >> 3, nch = a.cin >> 5;
+    const long long wbs_b = (long long)a.cout * 16, wts_b = (long long)cbt * wbs_b, wps_b = 9 * wts_b;
+    const unsigned wlane = (unsigned)(q4 * a.cout + c16) * 16u;
+
+    // this thread's share of a chunk image: words t, t + 256, ...; image order = LDS order
+    // [plane][cb][halo row][halo column]; out-of-map pixels (zero padding) read a clamped
+    // address and are zeroed after the load
+    unsigned soff[C2_NSTG];
+    unsigned sval = 0;
+#pragma unroll
+    for (int k = 0; k < C2_NSTG; ++k) {
+        const int e = min(t + 256 * k, C2_WORDS - 1);
+        const int plane = e / (C2_WORDS / 2), r1 = e - plane * (C2_WORDS / 2);
+        const int cb = r1 / (C2_HR * C2_PW), r2 = r1 - cb * (C2_HR * C2_PW);
+        const int hr = r2 / C2_PW, px = r2 - hr * C2_PW;
+        const int yy = y0 + hr - 1, xx = x0 + px - 1;
+        const bool ok = t + 256 * k < C2_WORDS && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w_;
+        sval |= ok ? 1u << k : 0u;
+        soff[k] = (unsigned)((((long long)plane * cbt + cb) * hw + (long long)min(max(yy, 0), a.h - 1) * a.w_ +
+                              min(max(xx, 0), a.w_ - 1)) * 16);
+    }
+    const char *ximg = reinterpret_cast<const char *>(a.x) + (long long)b * 2 * cbt * hw * 16;
+    const long long chunk_b = (long long)C2_CB * hw * 16;
+    u32x4 sreg[C2_NSTG];
+#define C2_STAGE(K, SRC)                                                                         \
+    do {                                                                                          \
+        u32x4 v_ = *reinterpret_cast<const u32x4 *>((SRC) + soff[K]);                             \
+        const u32x4 z_ = {0u, 0u, 0u, 0u};                                                        \
+        sreg[K] = (sval >> (K)) & 1u ? v_ : z_;                                                   \
+    } while (0)
+#define C2_COMMIT(LDS0)                                                                           \
+    do {                                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < C2_NSTG; ++k_)                                    \
+            if (t + 256 * k_ < C2_WORDS)                                                          \
+                *reinterpret_cast<u32x4 *>(xs + (LDS0) + (t + 256 * k_) * 16) = sreg[k_];         \
+    } while (0)
+    dance::static_for<0, C2_NSTG>([&](auto k) __attribute__((always_inline)) { C2_STAGE(decltype(k)::value, ximg); });
+    C2_COMMIT(0);
+    __syncthreads();
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char *wbase = reinterpret_cast<const char *>(a.w) + (long long)o0 * 16;
+    h8 ah[3][2], al[3][2];
+#define C2_LOAD_A(SLOT, PTR)                                                                      \
+    do {                                                                                          \
+        const char *pa_ = (PTR);                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                        \
+            ah[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wlane + i_ * 256);                 \
+            al[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + i_ * 256);         \
+        }                                                                                         \
+    } while (0)
+    C2_LOAD_A(0, wbase);
+    C2_LOAD_A(1, wbase + wts_b);
+
+    const unsigned lanebase = (unsigned)(q4 * C2_HR * C2_PW + c16) * 16u;
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const unsigned cur = (chunk & 1) * C2_BYTES, nxt = ((chunk + 1) & 1) * C2_BYTES;
+        const bool more = chunk + 1 < nch;
+        const char *ssrc = ximg + (more ? chunk + 1 : chunk) * chunk_b;     // last: valid dummy reads
+        const char *wchunk = wbase + (long long)chunk * C2_CB * wbs_b;
+        const unsigned pb = lanebase + cur;
+        h8 bh[4], bl[4];
+        // tile Q = tap * 8 + j: tap (ky, kx), j = (row j >> 2, columns 16 (j & 3) ..)
+#define C2_LOAD_B(Q)                                                                              \
+    do {                                                                                          \
+        constexpr int tap_ = (Q) / 8, j_ = (Q) % 8;                                               \
+        constexpr int imm_ = (((j_ >> 2) + tap_ / 3) * C2_PW + 16 * (j_ & 3) + tap_ % 3) * 16;    \
+        bh[(Q) % 4] = *reinterpret_cast<const h8 *>(xs + pb + imm_);                              \
+        bl[(Q) % 4] = *reinterpret_cast<const h8 *>(xs + pb + imm_ + C2_PLANE);                   \
+    } while (0)
+        C2_LOAD_B(0);
+        C2_LOAD_B(1);
+        C2_LOAD_B(2);
+        dance::static_for<0, 72>([&](auto qq) __attribute__((always_inline)) {
+            constexpr int q = decltype(qq)::value, tap = q / 8, j = q % 8;
+            if constexpr (j == 0) {
+                // weights two taps ahead (the last two taps fetch the next chunk's first two)
+                if constexpr (tap + 2 < 9)
+                    C2_LOAD_A((tap + 2) % 3, wchunk + (tap + 2) * wts_b);
+                else if (more)
+                    C2_LOAD_A((tap + 2) % 3, wchunk + C2_CB * wbs_b + (tap + 2 - 9) * wts_b);
+                // one staged activation load per tap, issued after the weight prefetch
+                C2_STAGE(tap, ssrc);
+            }
+            if constexpr (q + 3 < 72)
+                C2_LOAD_B(q + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tap % 3][0], bh[q % 4], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tap % 3][1], bh[q % 4], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][0], bl[q % 4], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][1], bl[q % 4], acc[1][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][0], bh[q % 4], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][1], bh[q % 4], acc[1][j], 0, 0, 0);
+        });
+#undef C2_LOAD_B
+        // the other buffer was last read for chunk - 1, which every wave left before the
+        // barrier that published this chunk: refill it, then publish
+        if (more)
+            C2_COMMIT(nxt);
+        __syncthreads();
+    }
+#undef C2_LOAD_A
+#undef C2_STAGE
+#undef C2_COMMIT
+
+    // epilogue: lane = pixel (row j >> 2, column 16 (j & 3) + c16), channels o0 + 16 i + 4 q4 .. + 3
+    const int nblk = a.cout >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float s1 = 0.0f, s2 = 0.0f;
+        float *yb = a.y + (((long long)b * nblk + ((o0 >> 4) + i)) * hw) * 16 + 4 * q4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int yy = y0 + (j >> 2), xx = x0 + 16 * (j & 3) + c16;
+            if (yy < a.h && xx < a.w_) {
+                const f32x4 v = acc[i][j] * a.winv;
+                *reinterpret_cast<f32x4 *>(yb + ((long long)yy * a.w_ + xx) * 16) = v;
+                s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+        }
+        // group = group_ch consecutive channels; a lane's 4 channels never straddle groups
+        // (group_ch is a multiple of 4): reduce over the lanes that share the group
+        const int gch = a.group_ch;
+#pragma unroll
+        for (int s = 1; s < 16; s <<= 1) {
+            s1 += __shfl_xor(s1, s, 64);
+            s2 += __shfl_xor(s2, s, 64);
+        }
+        if (gch >= 8) {                          // q4 pairs (8 channels) share a group
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+        }
+        if (gch >= 16) {                         // the whole 16-channel row tile shares a group
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+        }
+        const bool writer = c16 == 0 && (gch >= 16 ? q4 == 0 : (gch >= 8 ? (q4 & 1) == 0 : true));
+        if (writer) {
+            const int g = (o0 + 16 * i + 4 * q4) / gch;
+            double *st = a.stats + ((long long)b * (a.cout / gch) + g) * 2;
+            atomicAdd(st, (double)s1);
+            atomicAdd(st + 1, (double)s2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- GN + ReLU
+// y blocked fp32 -> GroupNorm(groups, eps) * gamma + beta -> ReLU -> P16 image (next conv)
+// or NHWC fp32 (gather input).  thread = one pixel of one 16-channel block, 4 channels each.
+struct GnArgs {
+    const float *y;
+    const double *stats;
+    const float *gamma, *beta;
+    float eps;
+    _Float16 *out16;        // P16 image or null
+    float *out_nhwc;        // (b, h, w, c) or null
+    int c, group_ch;
+    long long hw;
+};
+
+__global__ __launch_bounds__(256) void k_gn_relu(GnArgs a)
+{
+    // grid: (ceil(hw * 4 / 256), c / 16, b): thread -> (pixel, quarter of the 16-channel block)
+    const long long e = blockIdx.x * 256ll + threadIdx.x;
+    const long long p = e >> 2;
+    const int qtr = (int)(e & 3);
+    if (p >= a.hw)
+        return;
+    const int blk = blockIdx.y, b = blockIdx.z, nblk = a.c >> 4;
+    const int ch = blk * 16 + qtr * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(a.y + (((long long)b * nblk + blk) * a.hw + p) * 16 + qtr * 4);
+    const int g = ch / a.group_ch;
+    const double *st = a.stats + ((long long)b * (a.c / a.group_ch) + g) * 2;
+    const double cnt = (double)a.group_ch * (double)a.hw;
+    const double mean = st[0] / cnt;
+    double var = st[1] / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float mu = (float)mean;
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(a.gamma + ch);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(a.beta + ch);
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = (v[i] - mu) * rstd * ga[i] + be[i];
+        r[i] = x > 0.0f ? x : (x != x ? x : 0.0f);
+    }
+    if (a.out_nhwc) {
+        *reinterpret_cast<f32x4 *>(a.out_nhwc + ((long long)b * a.hw + p) * a.c + ch) = f32x4{r[0], r[1], r[2], r[3]};
+    } else {
+        // P16 image [b][plane][c/8][p][8]: this thread's 4 channels are half of one word
+        const int cbt = a.c >> 3, cb = ch >> 3, half4 = (ch >> 2) & 1;
+        h4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            _Float16 x, y;
+            dance::split_half(r[i], x, y);
+            hi[i] = x;
+            lo[i] = y;
+        }
+        _Float16 *d = a.out16 + (((long long)b * 2 * cbt + cb) * a.hw + p) * 8 + half4 * 4;
+        *reinterpret_cast<h4 *>(d) = hi;
+        *reinterpret_cast<h4 *>(d + (long long)cbt * a.hw * 8) = lo;
+    }
+}
+
+}  // namespace
+
+extern "C" int dance_nchw_to_p16img(const float *src, int c_total, int c_off, void *dst16, int b, int c,
+                                    int h, int w, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && c >= 8 && c % 8 == 0 && h >= 1 && w >= 1 && c_off >= 0 && c_off + c <= c_total);
+    if (b == 0)
+        return 0;
+    DANCE_REQUIRE(src && dst16 && b <= 65535 && c / 8 <= 65535);
+    const long long hw = (long long)h * w;
+    hipLaunchKernelGGL(k_nchw_to_p16img, dim3((unsigned)((hw + 255) / 256), c / 8, b), dim3(256), 0,
+                       (hipStream_t)stream, src, c_total, c_off, (_Float16 *)dst16, c, hw);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_scale, float *y_blocked,
+                                double *stats, int b, int cin, int cout, int h, int w, int groups,
+                                void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && h >= 1 && w >= 1);
+    DANCE_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 128 && cout % 128 == 0);
+    DANCE_REQUIRE(groups >= 1 && cout % groups == 0 && (cout / groups) % 4 == 0 &&
+                  (cout / groups == 4 || cout / groups == 8 || (cout / groups) % 16 == 0));
+    DANCE_REQUIRE((long long)h * w * (cin / 8) * 2 * 16 < (1ll << 32));      // 32-bit staging offsets
+    if (b == 0)
+        return 0;
+    DANCE_REQUIRE(x16 && w16 && y_blocked && stats);
+    Conv2dArgs a;
+    a.x = (const _Float16 *)x16; a.w = (const h8 *)w16; a.winv = w_inv_scale; a.y = y_blocked;
+    a.stats = stats; a.h = h; a.w_ = w; a.cin = cin; a.cout = cout; a.group_ch = cout / groups;
+    const long long tiles = (long long)b * ((h + 1) / 2) * ((w + 63) / 64);
+    DANCE_REQUIRE(tiles < (1ll << 31));
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)b * groups, (hipStream_t)stream);
+    if (e != hipSuccess)
+        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    const size_t lds = 2 * C2_BYTES;
+    e = hipFuncSetAttribute((const void *)k_conv3x3_16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    hipLaunchKernelGGL(k_conv3x3_16, dim3((unsigned)tiles, cout / 128), dim3(256), lds, (hipStream_t)stream, a);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamma,
+                             const float *beta, float eps, int groups, void *out16, float *out_nhwc,
+                             int b, int c, int h, int w, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && c >= 16 && c % 16 == 0 && h >= 1 && w >= 1);
+    DANCE_REQUIRE(groups >= 1 && c % groups == 0 && (c / groups) % 4 == 0);
+    DANCE_REQUIRE((out16 != nullptr) != (out_nhwc != nullptr));
+    if (b == 0)
+        return 0;
+    DANCE_REQUIRE(y_blocked && stats && gamma && beta && b <= 65535);
+    GnArgs a;
+    a.y = y_blocked; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.out16 = (_Float16 *)out16; a.out_nhwc = out_nhwc; a.c = c; a.group_ch = c / groups;
+    a.hw = (long long)h * w;
+    hipLaunchKernelGGL(k_gn_relu, dim3((unsigned)((a.hw * 4 + 255) / 256), c / 16, b), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return launch_check(__func__);
+}

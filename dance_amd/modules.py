@@ -18,6 +18,8 @@ output already is the NHWC layout the gather wants.
 Inference only: the training branch (target matching with Shapely/NumPy on the CPU,
 snake_head.py:982-1384) is outside the built path and raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -111,11 +113,36 @@ class _SnakeHeadBase(nn.Module):
             self._packed_sig = sig
         return self._packed
 
-    def _bottom(self, feats):
-        """bottom_out in channels_last; returns NHWC (B,Hf,Wf,C) contiguous memory."""
+    def _bottom_hip_layers(self, dev):
+        """bottom_out packed for the HIP feature-prep kernels, or None when this configuration
+        is outside what they cover (then the stock torch.nn modules run)."""
+        if os.environ.get("DANCE_FEATPREP", "hip") != "hip" or os.environ.get("DANCE_PRECISION", "fp16x3") != "fp16x3":
+            return None
+        for m in self.bottom_out:
+            if (m.norm is None or m.bias is not None or m.dilation != (1, 1) or m.in_channels != m.out_channels
+                    or m.in_channels % 128 != 0 or m.norm.num_groups != 32):
+                return None
+        sig = (dev,) + tuple(int(p._version) for m in self.bottom_out for p in m.parameters())
+        if getattr(self, "_bottom_sig", None) != sig:
+            layers = []
+            for m in self.bottom_out:
+                w16, s = ops.pack_conv3x3_weight16(m.weight.detach().float())
+                layers.append((w16, s, m.norm.weight.detach().float().contiguous(),
+                               m.norm.bias.detach().float().contiguous()))
+            self._bottom_layers, self._bottom_sig = layers, sig
+        return self._bottom_layers
+
+    def _bottom(self, feats_all, c_off):
+        """bottom_out (snake_head.py:1816-1820) on channels [c_off:] of the NCHW input; returns
+        NHWC (B,Hf,Wf,C) contiguous memory.  HIP path (conv3x3 + GroupNorm + ReLU in the
+        fast-mode arithmetic, writes NHWC directly); the stock modules in channels_last
+        otherwise."""
         if len(self.bottom_out) == 0:
             return None
-        x = feats.contiguous(memory_format=torch.channels_last)
+        layers = self._bottom_hip_layers(feats_all.device)
+        if layers is not None:
+            return ops.bottom_out16(feats_all, c_off, layers, groups=32, eps=self.bottom_out[0].norm.eps)
+        x = feats_all[:, c_off:].contiguous(memory_format=torch.channels_last)
         for conv in self.bottom_out:
             x = conv(x)
         x = x.permute(0, 2, 3, 1)
@@ -201,10 +228,10 @@ class RefineNet(_SnakeHeadBase):
         (feat NHWC, att plane); the re-concatenation of :1824 is never materialised."""
         d = self._get_deformer()
         if self.attention:
-            att, feats = features[:, 0].contiguous(), features[:, 1:]
+            att, feats, c_off = features[:, 0].contiguous(), features[:, 1:], 1
         else:
-            att, feats = None, features
-        nhwc = self._bottom(feats)
+            att, feats, c_off = None, features, 0
+        nhwc = self._bottom(features, c_off)
         if nhwc is None:
             nhwc, _ = ops.nchw_to_nhwc(feats.contiguous(), 0)
         return d, nhwc.float(), att
@@ -331,7 +358,7 @@ class DsnakeHead(_SnakeHeadBase):
         image_idx = torch.cat([b.new_empty(len(b)).fill_(i) for i, b in enumerate(boxes)])
         idx = image_idx.to(torch.int32)
         d = self._get_deformer()
-        nhwc = self._bottom(features)
+        nhwc = self._bottom(features, 0)
         if nhwc is None:
             nhwc, _ = ops.nchw_to_nhwc(features.contiguous(), 0)
         nhwc = nhwc.float()

@@ -231,3 +231,45 @@ def row_constant(g, wg, bias):
         check(lib().dance_row_constant(ptr(g), ptr(wg), ptr(bias), ptr(h), n, gd, cout,
                                        current_stream()), "row_constant")
     return h
+
+
+# ------------------------------------------------------------------------ feature prep
+def pack_conv3x3_weight16(weight):
+    """Conv2d weight (Cout, Cin, 3, 3) -> split-half packing (2, 9, Cin/8, Cout, 8), tap = ky*3+kx."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("3x3 kernels only")
+    return pack_conv_weight16(weight.reshape(cout, cin, 9))
+
+
+def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
+    """`RefineNet.bottom_out` (snake_head.py:562-615, 1816-1820): for every layer
+    Conv2d 3x3 (pad 1, no bias) -> GroupNorm(groups) -> ReLU, in the fast-mode arithmetic.
+
+    features (B, c_off + C, H, W) fp32 NCHW (channels before c_off, e.g. the attention map,
+    are skipped); layers = [(w16, scale_pow2, gamma, beta), ...] with w16 from
+    `pack_conv3x3_weight16`.  Returns the NHWC fp32 map (B, H, W, C) the gather kernels read."""
+    _need_gpu(features)
+    features = _f32c(features)
+    b, ct, h, w = features.shape
+    c = ct - c_off
+    dev = features.device
+    if not layers:
+        raise ValueError("no layers")
+    x16 = torch.empty((b, 2, c // 8, h, w, 8), dtype=torch.float16, device=dev)
+    yb = torch.empty((b, c // 16, h, w, 16), dtype=torch.float32, device=dev)
+    stats = torch.empty((b, groups, 2), dtype=torch.float64, device=dev)
+    out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = current_stream()
+        check(lib().dance_nchw_to_p16img(ptr(features), ct, c_off, ptr(x16), b, c, h, w, st), "nchw_to_p16img")
+        for i, (w16, scale, gamma, beta) in enumerate(layers):
+            if w16.shape[2] * 8 != c or w16.shape[3] != c:
+                raise ValueError("bottom_out layers are C -> C")
+            check(lib().dance_conv3x3_16(ptr(x16), ptr(w16), 1.0 / scale, ptr(yb), ptr(stats), b, c, c, h, w,
+                                         groups, st), "conv3x3_16")
+            last = i + 1 == len(layers)
+            check(lib().dance_gn_relu(ptr(yb), ptr(stats), ptr(gamma), ptr(beta), eps, groups,
+                                      None if last else ptr(x16), ptr(out) if last else None, b, c, h, w, st),
+                  "gn_relu")
+    return out

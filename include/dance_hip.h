@@ -62,6 +62,30 @@ int dance_roll_array(const float *array, const int64_t *step, float *new_array, 
  * mid-points (p[i] + p[i+1 mod v]) / 2, rounded as the reference's add-then-divide. */
 int dance_contour_upsample_2x(const float *loc, float *out, int n, int v, void *stream);
 
+/* ----------------------------------------------- feature prep ------ */
+/* reference: RefineNet.bottom_out, snake_head.py:562-615 (construction: Conv2d 3x3, padding 1,
+ * bias = not norm, GroupNorm(32, C), ReLU) and 1816-1820 (use, timer scope snake_feat_prep).
+ * The three entry points below are one bottom_out layer in the split-half fp16 arithmetic of
+ * the fast mode (fp32-level accuracy); dilation 1 only.
+ *
+ * dance_nchw_to_p16img: channels [c_off, c_off + c) of src (b, c_total, h, w) fp32 ->
+ *   dst16 "P16 image" [b][plane hi/lo][c/8][h][w][8] fp16 (4 bytes per element). */
+int dance_nchw_to_p16img(const float *src, int c_total, int c_off, void *dst16, int b, int c,
+                         int h, int w, void *stream);
+/* dance_conv3x3_16: raw 3x3 convolution (zero padding 1, no bias) of a P16 image with weights
+ *   packed [plane][tap ky*3+kx][cin/8][cout][8] fp16 of w * 2^s (w_inv_scale = 2^-s).
+ *   y_blocked (b, cout/16, h, w, 16) fp32; stats (b, groups, 2) f64 = per-group sum and sum of
+ *   squares of y (zeroed here, on the stream). */
+int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_scale, float *y_blocked,
+                     double *stats, int b, int cin, int cout, int h, int w, int groups,
+                     void *stream);
+/* dance_gn_relu: GroupNorm(groups, eps) * gamma + beta, then ReLU, of y_blocked using stats;
+ *   exactly one of out16 (P16 image, the next layer's input) / out_nhwc ((b, h, w, c) fp32,
+ *   what the gather kernels read) is non-null. */
+int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamma,
+                  const float *beta, float eps, int groups, void *out16, float *out_nhwc,
+                  int b, int c, int h, int w, void *stream);
+
 /* ------------------------------------------------- contour initialisation (a11-a15) - */
 enum {
     DANCE_POLY_RAW = 0,      /* src = polygons (n,e,2)                                  */

@@ -351,6 +351,24 @@ def gen_upsample2x(sh):
     _save("g7_upsample2x", **out)
 
 
+def gen_bottom_out(sh):
+    """The reference's own `RefineNet.bottom_out` ModuleList (snake_head.py:562-615) as
+    `single_test` runs it (1816-1820) on a small seeded map; weights from the seed."""
+    cfg = ref_loader.dance_cfg(num_sampling=128, num_convs=2)
+    ref = sh.RefineNet(cfg).eval()
+    sd = ref.state_dict()
+    ck = synthetic.fill_state_dict_(sd, WEIGHT_SEED)
+    ref.load_state_dict(sd)
+    feats = synthetic.make_smooth_features(2, 256, 9, 70, 31, attention=False, cell=4)
+    with torch.no_grad():
+        x = feats
+        for i in range(ref.num_convs):
+            x = ref.bottom_out[i](x)
+    mine = snake_ref.bottom_out({k: v for k, v in sd.items()}, feats)
+    _close(mine, x, 1e-5, "bottom_out")
+    _save("g8_bottom_out", weight_seed=WEIGHT_SEED, weight_checksum=ck, feat_seed=31, out=x)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -364,6 +382,7 @@ def main():
     gen_dance(sh)
     gen_dsnake(dh)
     gen_upsample2x(sh)
+    gen_bottom_out(sh)
     print("golden vectors written to", os.path.normpath(OUT))
 
 

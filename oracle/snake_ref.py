@@ -113,6 +113,20 @@ def contour_upsample_2x(locations):
     return new
 
 
+def bottom_out(sd_all, features, groups=32, eps=1e-5):
+    """RefineNet.bottom_out, snake_head.py:562-615 / 1816-1820: Conv2d(3x3, padding 1, no bias)
+    -> GroupNorm(32) -> ReLU per layer (detectron2's Conv2d wrapper: conv, norm, activation).
+    sd_all holds bottom_out.{i}.weight, bottom_out.{i}.norm.{weight,bias}."""
+    import torch.nn.functional as F
+    x, i = features, 0
+    while "bottom_out.%d.weight" % i in sd_all:
+        x = F.conv2d(x, sd_all["bottom_out.%d.weight" % i], None, padding=1)
+        x = F.group_norm(x, groups, sd_all["bottom_out.%d.norm.weight" % i], sd_all["bottom_out.%d.norm.bias" % i], eps)
+        x = F.relu(x)
+        i += 1
+    return x
+
+
 # ------------------------------------------------------------------------------- gather
 def get_locations_feature(features, locations, image_idx, padding_mode):
     """snake_head.py:1542-1578 (padding_mode="reflection") and dsnake_head.py:670-695

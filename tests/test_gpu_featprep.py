@@ -1,0 +1,64 @@
+"""GPU: RefineNet.bottom_out (conv3x3 + GroupNorm + ReLU) on the HIP path,
+against the golden output of the reference's own module and against the torch-CPU oracle."""
+import pytest
+import torch
+
+from _util import golden, rel_err
+from dance_amd import config, modules, ops, synthetic
+from oracle import snake_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _state_dict(seed):
+    cfg = config.dance_r50(num_sampling=128, num_convs=2)
+    net = modules.RefineNet(cfg)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    return cfg, sd, synthetic.fill_state_dict_(sd, seed)
+
+
+def _layers(sd, device, n=2):
+    out = []
+    for i in range(n):
+        w16, s = ops.pack_conv3x3_weight16(sd["bottom_out.%d.weight" % i].to(device))
+        out.append((w16, s, sd["bottom_out.%d.norm.weight" % i].to(device).contiguous(),
+                    sd["bottom_out.%d.norm.bias" % i].to(device).contiguous()))
+    return out
+
+
+def test_bottom_out_golden(device):
+    g = golden("g8_bottom_out")
+    cfg, sd, ck = _state_dict(int(g["weight_seed"]))
+    assert abs(ck - float(g["weight_checksum"])) < 1e-6 * ck
+    feats = synthetic.make_smooth_features(2, 256, 9, 70, int(g["feat_seed"]), attention=False, cell=4)
+    got = ops.bottom_out16(feats.to(device), 0, _layers(sd, device))
+    want = g["out"].permute(0, 2, 3, 1)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 64), (2, 7, 65), (1, 5, 130), (3, 4, 3)])
+def test_bottom_out_shapes_vs_oracle(device, shape):
+    """partial tiles in both directions, odd heights, attention channel skipped, one layer and two"""
+    b, h, w = shape
+    cfg, sd, _ = _state_dict(5)
+    feats = synthetic.make_features(b, 256, h, w, 100 + w, attention=True)
+    for n in (1, 2):
+        sub = {k: v for k, v in sd.items() if k.startswith("bottom_out.") and int(k.split(".")[1]) < n}
+        want = snake_ref.bottom_out(sub, feats[:, 1:]).permute(0, 2, 3, 1)
+        got = ops.bottom_out16(feats.to(device), 1, _layers(sd, device, n))
+        assert rel_err(got, want) < 1e-4, (shape, n)
+
+
+def test_module_bottom_out_feeds_the_gather(device):
+    """the drop-in module runs its bottom_out on the HIP path and hands NHWC to the deformer"""
+    cfg, sd, _ = _state_dict(7)
+    net = modules.RefineNet(cfg)
+    net.load_state_dict(sd)
+    net = net.to(device).eval()
+    feats = synthetic.make_smooth_features(2, 256, 24, 40, 9)
+    d, nhwc, att = net._features(feats.to(device))
+    want = snake_ref.bottom_out(sd, feats[:, 1:]).permute(0, 2, 3, 1)
+    assert nhwc.shape == want.shape and nhwc.is_contiguous()
+    assert rel_err(nhwc, want) < 1e-4
+    assert torch.equal(att.cpu(), feats[:, 0])
