@@ -52,6 +52,7 @@ def parse():
                     help="fp16x3 (default): split-half operands, 3 f16 MFMAs per product, fp32 "
                          "accumulate (fp32-level accuracy); fp32: exact-fp32 MFMA kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-feat-prep", action="store_true", help="skip the untimed bottom_out measurement")
     ap.add_argument("--cpu-reps", type=int, default=40,
                     help="timed oracle runs of config 1 (about 10 s of CPU work in total)")
     return ap.parse_args()
@@ -192,6 +193,46 @@ def main():
         g1.record()
         torch.cuda.synchronize()
         sampling_ms = g0.elapsed_time(g1) / 10
+        # the reference's `snake_feat_prep` scope (snake_head.py:1816-1820): bottom_out =
+        # 2 x [conv3x3 256->256 + GroupNorm(32) + ReLU] on the same maps, HIP path vs stock torch.nn
+        feat_prep = None
+        if not args.no_feat_prep:
+            cfg2 = config.dance_r50(num_sampling=v, num_convs=2)
+            net2 = modules.RefineNet(cfg2)
+            sd2 = {k: t.clone() for k, t in net2.state_dict().items()}
+            synthetic.fill_state_dict_(sd2, 1234)
+            net2.load_state_dict(sd2)
+            net2 = net2.to(dev).eval()
+            layers = net2._bottom_hip_layers(dev)
+
+            def stock():
+                x = feats[:, 1:].contiguous(memory_format=torch.channels_last)
+                for conv in net2.bottom_out:
+                    x = conv(x)
+                return x.permute(0, 2, 3, 1).contiguous()
+
+            def timed(fn, reps):
+                for _ in range(2):
+                    fn()
+                g0.record()
+                for _ in range(reps):
+                    fn()
+                g1.record()
+                torch.cuda.synchronize()
+                return g0.elapsed_time(g1) / reps
+
+            with torch.no_grad():
+                hip_ms = timed(lambda: ops.bottom_out16(feats, 1, layers), 5)
+                stock_ms = timed(stock, 3)
+            fp_flops = 2 * 2.0 * CH * CH * 9 * HF * WF * b
+            feat_prep = {"stage": "bottom_out: 2 x [conv3x3 %d->%d + GroupNorm(32) + ReLU] on (%d,%d,%d,%d), "
+                                  "NHWC fp32 out; outside the timed step" % (CH, CH, b, CH, HF, WF),
+                         "kernel": "k_conv3x3_16 (split-half f16 MFMA implicit GEMM) + k_gn_relu",
+                         "ms": hip_ms, "algorithmic_TFLOPs": fp_flops / hip_ms / 1e9,
+                         "executed_f16_TFLOPs": 3 * fp_flops / hip_ms / 1e9,
+                         "frac_of_f16_peak": 3 * fp_flops / hip_ms / 1e9 / PEAK_F16_MFMA_TFLOPS,
+                         "stock_torch_ms": stock_ms, "speedup_vs_stock": stock_ms / hip_ms}
+            del net2, layers
 
     if rank == 0:
         # per-stage device time from the HIP events recorded inside the timed steps
@@ -257,6 +298,7 @@ def main():
                                                       / PEAK_HBM_GBPS},
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms),
+            "feat_prep": feat_prep,
             "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,
                                  "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),
                                  "note": "reference scope `contour_sampling`, outside the timed step"},
