@@ -72,10 +72,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c16 = lane & 15, q4 = lane >> 4;
     const int tiles_x = (a.w_ + 63) >> 6, rows2 = (a.h + 1) >> 1;
-    const int bid = blockIdx.x;
+    // the output-channel tile is the fast grid index: the workgroups that share an input
+    // tile run together and the second one finds it in L2
+    const int mtiles = a.cout >> 7;
+    const int mt = blockIdx.x % mtiles, bid = blockIdx.x / mtiles;
     const int tx = bid % tiles_x, ty = (bid / tiles_x) % rows2, b = bid / (tiles_x * rows2);
     const int x0 = tx * 64, y0 = ty * 2;
-    const int o0 = blockIdx.y * 128 + wave * 32;
+    const int o0 = mt * 128 + wave * 32;
     const long long hw = (long long)a.h * a.w_;
     const int cbt = a.cin >> 3, nch = a.cin >> 5;
     const long long wbs_b = (long long)a.cout * 16, wts_b = (long long)cbt * wbs_b, wps_b = 9 * wts_b;
@@ -321,7 +324,7 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
     a.x = (const _Float16 *)x16; a.w = (const h8 *)w16; a.winv = w_inv_scale; a.y = y_blocked;
     a.stats = stats; a.h = h; a.w_ = w; a.cin = cin; a.cout = cout; a.group_ch = cout / groups;
     const long long tiles = (long long)b * ((h + 1) / 2) * ((w + 63) / 64);
-    DANCE_REQUIRE(tiles < (1ll << 31));
+    DANCE_REQUIRE(tiles * (cout / 128) < (1ll << 31));
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)b * groups, (hipStream_t)stream);
     if (e != hipSuccess)
         return dance::fail((int)e, __func__, hipGetErrorString(e));
@@ -329,7 +332,7 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
     e = hipFuncSetAttribute((const void *)k_conv3x3_16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return dance::fail((int)e, __func__, hipGetErrorString(e));
-    hipLaunchKernelGGL(k_conv3x3_16, dim3((unsigned)tiles, cout / 128), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_conv3x3_16, dim3((unsigned)(tiles * (cout / 128))), dim3(256), lds, (hipStream_t)stream, a);
     return launch_check(__func__);
 }
 
