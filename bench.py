@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--precision", choices=("fp16x3", "fp32"), default="fp16x3",
                     help="fp16x3 (default): split-half operands, 3 f16 MFMAs per product, fp32 "
                          "accumulate (fp32-level accuracy); fp32: exact-fp32 MFMA kernels")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="deform the contours in this many parts on separate HIP streams (no per-stage "
+                         "events then; measured -4 %% wall with 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-feat-prep", action="store_true", help="skip the untimed bottom_out measurement")
     ap.add_argument("--cpu-reps", type=int, default=40,
@@ -144,7 +147,8 @@ def main():
                 lev[1].record()
         else:
             f = pre
-        preds = deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", stage_events=ev)
+        preds = deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc",
+                                stage_events=ev if args.streams == 1 else None, streams=args.streams)
         return all_gather_contours(preds[-1])
 
     for _ in range(args.warmup):
@@ -166,6 +170,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (world * n, v, 2) and bool(torch.isfinite(out).all())
+    if args.streams > 1 and rank == 0:
+        # per-stage events cannot be read off overlapping streams: one instrumented
+        # single-stream pass after the timed region fills the per-kernel durations
+        for k in range(args.steps):
+            f = deformer.prepare_features(feats) if pre is None else pre
+            deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", stage_events=events[k])
+        torch.cuda.synchronize()
 
     # the gather stage on its own (k_gather: 4 taps x 257 channels per vertex -> (N, 258, V)),
     # outside the timed region: the HBM-bound form of the stage that k_gather_head* fuses
@@ -298,6 +309,7 @@ def main():
                                                       / PEAK_HBM_GBPS},
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms),
+            "streams": args.streams,
             "feat_prep": feat_prep,
             "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,
                                  "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),

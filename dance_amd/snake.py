@@ -155,6 +155,7 @@ class ContourDeformer:
             raise ValueError("precision must be 'fp16x3' or 'fp32'")
         self.precision = precision
         self.nets = list(nets)
+        self._padding_name, self._deloc_name, self._side = padding, de_loc_type, None
         self.padding = ops.PAD_REFLECTION if padding == "reflection" else ops.PAD_ZEROS
         self.deloc = ops.DELOC[de_loc_type]
         self.individual_scale = bool(individual_scale)
@@ -173,6 +174,31 @@ class ContourDeformer:
         (feat NHWC (B,Hf,Wf,C), att (B,Hf,Wf) or None).  The split replaces
         snake_head.py:1812-1814; the re-concatenation of :1824 never happens."""
         return ops.nchw_to_nhwc(features, 1 if self.attention else 0)
+
+    def _deform_streams(self, features, init_contours, image_idx, image_sizes, whs, layout, k):
+        feat_att = self.prepare_features(features) if layout == "nchw" else features
+        n = init_contours.size(0)
+        cuts = [n * i // k for i in range(k + 1)]
+        cur = torch.cuda.current_stream(init_contours.device)
+        if getattr(self, "_side", None) is None or len(self._side) != k:
+            # every part needs its own workspace: one helper deformer (sharing the packed nets) per stream
+            self._side = [(torch.cuda.Stream(init_contours.device),
+                           ContourDeformer(self.nets, self._padding_name, self._deloc_name, self.individual_scale,
+                                           self.attention, self.fused_head, self.precision)) for _ in range(k)]
+        parts = []
+        for i, (st, d) in enumerate(self._side):
+            d.MAX_CHUNK = self.MAX_CHUNK
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                sl = slice(cuts[i], cuts[i + 1])
+                parts.append(d.deform(feat_att, init_contours[sl], image_idx[sl], image_sizes,
+                                      None if whs is None else whs[sl], layout="nhwc"))
+        for st, _ in self._side:
+            cur.wait_stream(st)
+        for p in parts:
+            for t in p:
+                t.record_stream(cur)
+        return [torch.cat([p[i] for p in parts]) for i in range(len(self.nets))]
 
     def evolve(self, it, feat, att, locations, image_idx, whs, *, use_att, clip_first, clip_max,
                x_in=None, out=None, stage_events=None):
@@ -222,7 +248,7 @@ class ContourDeformer:
         return out
 
     def deform(self, features, init_contours, image_idx, image_sizes, whs, layout="nchw",
-               stage_events=None):
+               stage_events=None, streams=1):
         """features: NCHW (B,[1+]C,Hf,Wf) as the reference's evolve loop sees it after
         `bottom_out` (+ attention map in channel 0), or with layout="nhwc" the pair
         (feat NHWC, att) from `prepare_features`.
@@ -232,7 +258,14 @@ class ContourDeformer:
 
         Reference driver: snake_head.py:1822-1862 (single image) / 1969-1995 (batched).
         `clip_locations` (1715-1727) is reproduced as it behaves: with image_idx None only
-        contour 0 is clamped to the image; with a tensor image_idx nothing is clamped."""
+        contour 0 is clamped to the image; with a tensor image_idx nothing is clamped.
+
+        streams > 1: the contours are split into that many contiguous parts, each deformed
+        (all iterations) on its own HIP stream -- contours are independent, so one part's kernel
+        tails and launch gaps overlap the other's kernels (measured: 2 streams -4 % wall on
+        config 2; results bit-identical)."""
+        if streams > 1 and init_contours.size(0) >= 2 * streams and stage_events is None and image_idx is not None:
+            return self._deform_streams(features, init_contours, image_idx, image_sizes, whs, layout, streams)
         if layout == "nchw":
             feat, att = self.prepare_features(features)
         else:

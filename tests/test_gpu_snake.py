@@ -239,8 +239,9 @@ def test_deterministic_and_chunked(device):
     d2 = snake.ContourDeformer(nets)
     d2.MAX_CHUNK = 16
     c = d2.deform(feats, loc, idx, [(200, 304)] * 3, whs)
+    e = d.deform(feats, loc, idx, [(200, 304)] * 3, whs, streams=2)      # two HIP streams
     for i in range(3):
-        assert torch.equal(a[i], b[i]) and torch.equal(a[i], c[i])
+        assert torch.equal(a[i], b[i]) and torch.equal(a[i], c[i]) and torch.equal(a[i], e[i])
     want = snake_ref.dance_deform(sd, feats.cpu(), loc.cpu(), idx.cpu(), [(200, 304)] * 3, whs.cpu())
     for i in range(3):
         assert coord_rel_err(a[i], want[i]) < REL_TOL
