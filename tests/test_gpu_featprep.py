@@ -62,3 +62,25 @@ def test_module_bottom_out_feeds_the_gather(device):
     assert nhwc.shape == want.shape and nhwc.is_contiguous()
     assert rel_err(nhwc, want) < 1e-4
     assert torch.equal(att.cpu(), feats[:, 0])
+
+
+def test_dsnake_module_with_bottom_out(device):
+    """DsnakeHead end to end with NUM_CONVS = 2 (dsnake_head.py:788-830): HIP feature prep ->
+    init -> octagon -> 3 evolves, against the oracle's composition of the same stages."""
+    from _util import REL_TOL, FakeBoxes, FakeInstances, coord_rel_err
+    cfg = config.dsnake_r50(num_convs=2)
+    head = modules.DsnakeHead(cfg)
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    synthetic.fill_state_dict_(sd, 21)
+    head.load_state_dict(sd)
+    head = head.to(device).eval()
+    hf, wf = 40, 56
+    feats = synthetic.make_smooth_features(2, 256, hf, wf, 5, attention=False)
+    boxes = synthetic.make_boxes(10, hf * 4, wf * 4, 6, r_min=10, r_max=50).view(2, 5, 4)
+    insts = [FakeInstances((hf * 4, wf * 4), pred_boxes=FakeBoxes(boxes[i].to(device))) for i in range(2)]
+    with torch.no_grad():
+        res, _ = head(feats.to(device), insts, None)
+    got = torch.cat([r.pred_polys.tensor for r in res])
+    prepped = snake_ref.bottom_out(sd, feats)
+    want = snake_ref.dsnake_deform(sd, prepped, [boxes[0], boxes[1]])
+    assert coord_rel_err(got, want["preds"][-1]) < REL_TOL
