@@ -239,7 +239,10 @@ class RefineNet(_SnakeHeadBase):
     def deform(self, features, locations, image_idx, image_sizes, whs):
         """The `snake_deformation` scope (snake_head.py:1822-1862): per-iteration contours."""
         d, nhwc, att = self._features(features)
-        return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc")
+        # DANCE_STREAMS=2: halves of the contours on two HIP streams (bit-identical, ~8 % faster
+        # on large batches; ContourDeformer.deform)
+        return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc",
+                        streams=int(os.environ.get("DANCE_STREAMS", "1")))
 
     def single_test(self, features, pred_instances):
         """snake_head.py:1763-1869 (one image)."""
