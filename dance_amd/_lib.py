@@ -65,6 +65,7 @@ SIGNATURES = {
     "dance_nchw_to_p16img": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "dance_conv3x3_16": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_nms_sorted": (c_int, [P, c_int, c_float, P, P, P, P]),
     "dance_contour_upsample_2x": (c_int, [P, P, c_int, c_int, P]),
     "dance_uniform_upsample": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P]),
     "dance_nchw_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -304,6 +304,101 @@ extern "C" int dance_roll_array(const float *array, const int64_t *step, float *
 }
 
 // ------------------------------------------------------------------------------------
+// nms (utils.h:36-43, nms.cu:13-128): IoU bit mask over 64 x 64 tiles of the score-sorted
+// boxes, then the greedy sweep -- on the device (the reference copies the mask to the host).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float nms_iou(const float *a, const float *b)
+{
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+    const float interS = width * height;
+    const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+    const float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+    return interS / (Sa + Sb - interS);
+}
+
+// grid (col_blocks, col_blocks), 64 threads; mask[i][col] bit j = IoU(box i, box 64 col + j) > thresh
+// for j later than i in the sorted order (nms.cu:23-67)
+__global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float *__restrict__ boxes,
+                                                 unsigned long long *__restrict__ mask)
+{
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
+    __shared__ float bb[64 * 5];
+    if ((int)threadIdx.x < col_size)
+        for (int k = 0; k < 5; ++k)
+            bb[threadIdx.x * 5 + k] = boxes[(64ll * col_start + threadIdx.x) * 5 + k];
+    __syncthreads();
+    if ((int)threadIdx.x < row_size) {
+        const int cur = 64 * row_start + threadIdx.x;
+        const float *cb = boxes + 5ll * cur;
+        unsigned long long t = 0;
+        const int start = row_start == col_start ? threadIdx.x + 1 : 0;
+        for (int i = start; i < col_size; ++i)
+            if (nms_iou(cb, bb + i * 5) > thresh)
+                t |= 1ULL << i;
+        mask[(long long)cur * gridDim.x + col_start] = t;
+    }
+}
+
+// one wavefront: blocks of 64 boxes in order.  Inside a block the 64 decisions are serial but
+// touch only the block's diagonal mask words (one per lane); the kept rows are then OR-ed
+// into the removal words of the later blocks, lanes across the columns (nms.cu:105-121).
+__global__ __launch_bounds__(64) void k_nms_sweep(int n, int col_blocks, const unsigned long long *__restrict__ mask,
+                                                  unsigned long long *__restrict__ remv, long long *__restrict__ keep,
+                                                  int *__restrict__ count)
+{
+    const int lane = threadIdx.x;
+    for (int j = lane; j < col_blocks; j += 64)
+        remv[j] = 0;
+    __syncthreads();
+    int num = 0;
+    for (int kb = 0; kb < col_blocks; ++kb) {
+        const int row = kb * 64 + lane, size = min(n - kb * 64, 64);
+        const unsigned long long diag = lane < size ? mask[(long long)row * col_blocks + kb] : 0ull;
+        unsigned long long r = remv[kb], kept = 0;
+        for (int i = 0; i < size; ++i) {
+            const unsigned long long di = __shfl(diag, i, 64);
+            if (!((r >> i) & 1ull)) {
+                kept |= 1ull << i;
+                r |= di;
+            }
+        }
+        if (lane < size && ((kept >> lane) & 1ull))
+            keep[num + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+        num += __popcll(kept);
+        for (int j = kb + 1 + lane; j < col_blocks; j += 64) {
+            unsigned long long acc = remv[j];
+            for (int i = 0; i < size; ++i)
+                if ((kept >> i) & 1ull)
+                    acc |= mask[(long long)(kb * 64 + i) * col_blocks + j];
+            remv[j] = acc;
+        }
+        __syncthreads();
+    }
+    if (lane == 0)
+        *count = num;
+}
+
+extern "C" int dance_nms_sorted(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
+                                int64_t *keep, int32_t *count, void *stream)
+{
+    DANCE_REQUIRE(n >= 0 && n <= (1 << 20));
+    DANCE_REQUIRE(count != nullptr);
+    if (n == 0)
+        return hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess
+                   ? 0 : dance::fail((int)hipErrorUnknown, __func__, "memset failed");
+    DANCE_REQUIRE(boxes_sorted && mask_ws && keep);
+    const int cb = (n + 63) / 64;
+    unsigned long long *mask = (unsigned long long *)mask_ws;
+    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, (hipStream_t)stream, n, thresh, boxes_sorted, mask);
+    hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, (hipStream_t)stream, n, cb, mask,
+                       mask + (long long)n * cb, (long long *)keep, count);
+    return launch_check(__func__);
+}
+
+// ------------------------------------------------------------------------------------
 // contour_upsample_2x (snake_head.py:1752-1761): out[2i] = p[i], out[2i+1] = (p[i] + p[i+1 mod V]) / 2
 // (one fp32 add, one exact halving -- this file is compiled with contraction off)
 // ------------------------------------------------------------------------------------

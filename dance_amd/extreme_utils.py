@@ -1,10 +1,11 @@
 """Drop-in for the reference's `core.layers.extreme_utils` (`_ext`) module.
 
-Same four function names, argument order, dtypes, in-place behaviour and error type
-(RuntimeError for non-GPU tensors and shape mismatches, with the reference's messages:
-core/layers/extreme_utils/src/utils.cu:162-184, 263-280, 338-348, 408-417), but backed by
-the hand-written gfx950 kernels of libdance_hip.so through its C ABI.  `nms` (utils.h:36-43)
-is not on the contour path and has no caller in the reference; it is not provided.
+Same five function names (utils.cpp:4-10), argument order, dtypes, in-place behaviour and
+error type (RuntimeError for non-GPU tensors and shape mismatches, with the reference's
+messages: core/layers/extreme_utils/src/utils.cu:162-184, 263-280, 338-348, 408-417), but
+backed by the hand-written gfx950 kernels of libdance_hip.so through its C ABI.  `nms`
+(utils.h:36-43) is not on the contour path and has no caller in the reference; it is
+provided so that the whole `_ext` surface is covered.
 
 A maintainer swaps it in with one line in core/layers/__init__.py:4
     from dance_amd import extreme_utils
@@ -100,3 +101,28 @@ def roll_array(array, step):
         check(lib().dance_roll_array(ptr(a), ptr(s), ptr(out), b, n, d, current_stream()),
               "roll_array")
     return out
+
+
+def nms(dets, scores, threshold):
+    """utils.h:36-43 -> ascending int64 indices of the boxes that survive greedy NMS
+    ("+1" IoU convention, strict > threshold).  dets (n,4) f32 xyxy, scores (n,) f32, on the
+    GPU; like the reference, an empty input returns an empty CPU tensor, otherwise the
+    result lives on the device.  Sorting is torch's (as the reference uses at::sort); the
+    mask and the sweep run in libdance_hip.so, without the reference's host round trip
+    (one 4-byte count is read back to size the result)."""
+    if dets.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    _assert(dets.is_cuda, "boxes must be a CUDA tensor")
+    _assert(dets.dim() == 2 and dets.size(1) == 4 and scores.dim() == 1 and scores.size(0) == dets.size(0),
+            "dets must be (n, 4) and scores (n,)")
+    n = dets.size(0)
+    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    boxes = torch.cat([dets.float(), scores.float()[:, None]], 1)[order].contiguous()
+    cb = (n + 63) // 64
+    ws = torch.empty(((n + 1) * cb,), dtype=torch.int64, device=dets.device)
+    keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    with torch.cuda.device(dets.device):
+        check(lib().dance_nms_sorted(ptr(boxes), n, float(threshold), ptr(ws), ptr(keep), ptr(count),
+                                     current_stream()), "nms")
+    return torch.sort(order[keep[:int(count.item())]])[0]

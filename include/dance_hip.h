@@ -57,6 +57,15 @@ int dance_calculate_wnp(const int64_t *edge_num, const int64_t *edge_start_idx,
 int dance_roll_array(const float *array, const int64_t *step, float *new_array, int b,
                      int n, int d, void *stream);
 
+/* reference: `nms` of the same pybind module (utils.cpp:9, utils.h:36-43, src/nms.cu:13-128;
+ * exported, not called by the reference's Python).  boxes_sorted (n,5) f32 = x1,y1,x2,y2,score
+ * in descending score order (the reference sorts with at::sort before its kernel, nms.cu:74-76;
+ * the Python shim does the same).  "+1" IoU, strict > thresh.  mask_ws: (n + 1) * ceil(n/64)
+ * uint64 of scratch.  keep (n) i64 receives the kept positions in the sorted order, ascending;
+ * count (1) i32 their number.  The sweep runs on the device: no host copy of the mask. */
+int dance_nms_sorted(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
+                     int64_t *keep, int32_t *count, void *stream);
+
 /* reference: snake_head.py:1752-1761 (`RefineNet.contour_upsample_2x`, used only with
  * LAST_UP_SAMPLE).  loc (n,v,2) f32 -> out (n,2v,2): even slots copy, odd slots are the
  * mid-points (p[i] + p[i+1 mod v]) / 2, rounded as the reference's add-then-divide. */

@@ -22,6 +22,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* utils.cu:9-17.  float math throughout; the caller compares the result against a
@@ -195,6 +196,40 @@ void ref_roll_array(const float *array, const int64_t *step, float *new_array, i
                    array + ((int64_t)ib * n + in) * d, sizeof(float) * (size_t)d);
         }
     }
+}
+
+/* nms.cu:13-21 (devIoU, "+1" pixel convention, fp32, no contraction) and nms.cu:70-128
+ * (nms_cuda): boxes (n,5) = x1,y1,x2,y2,score ALREADY sorted by descending score
+ * (nms.cu:74-76 sorts before the kernel); greedy sweep in that order, a box is dropped when
+ * its IoU with an earlier kept box is > thresh (strict).  keep receives the kept positions
+ * (indices into the sorted order, ascending); returns their number. */
+static float ref_iou(const float *a, const float *b)
+{
+    float left = a[0] > b[0] ? a[0] : b[0], right = a[2] < b[2] ? a[2] : b[2];
+    float top = a[1] > b[1] ? a[1] : b[1], bottom = a[3] < b[3] ? a[3] : b[3];
+    float width = right - left + 1, height = bottom - top + 1;
+    width = width > 0.f ? width : 0.f;
+    height = height > 0.f ? height : 0.f;
+    float interS = width * height;
+    float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
+    float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+    return interS / (Sa + Sb - interS);
+}
+
+int ref_nms_sorted(const float *boxes, int n, float thresh, int64_t *keep)
+{
+    int num = 0;
+    unsigned char *removed = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    for (int i = 0; i < n; ++i) {
+        if (removed[i])
+            continue;
+        keep[num++] = i;
+        for (int j = i + 1; j < n; ++j)
+            if (ref_iou(boxes + 5 * i, boxes + 5 * j) > thresh)
+                removed[j] = 1;
+    }
+    free(removed);
+    return num;
 }
 
 /* ------------------------------------------------------------------------------------

@@ -77,6 +77,20 @@ def roll_array(array, step):
     return out
 
 
+def nms(dets, scores, threshold):
+    """utils.h:36-43 + nms.cu:70-128: dets (n,4), scores (n,) -> ascending int64 indices of
+    the kept boxes.  Ties in the scores are broken by a stable sort here (the reference's
+    unstable device sort leaves them unspecified)."""
+    if dets.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    b = torch.cat([dets.float(), scores.float()[:, None]], 1)[order].contiguous()
+    keep = torch.zeros((b.size(0),), dtype=torch.int64)
+    lib().ref_nms_sorted.restype = ctypes.c_int
+    num = lib().ref_nms_sorted(_p(b), b.size(0), ctypes.c_float(float(threshold)), _p(keep))
+    return torch.sort(order[keep[:num]])[0]
+
+
 def uniform_upsample_fused(poly, p_num):
     """C restatement of RefineNet.uniform_upsample (snake_head.py:764-794) as one routine.
 

@@ -149,3 +149,34 @@ def test_contour_upsample_2x_golden_bit_exact(device):
     big = torch.rand((3000, 128, 2)) * 1000
     from oracle import snake_ref
     assert torch.equal(ops.contour_upsample_2x(big.to(device)).cpu(), snake_ref.contour_upsample_2x(big))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 2000])
+@pytest.mark.parametrize("thresh", [0.3, 0.6])
+def test_nms_vs_c_oracle(device, n, thresh):
+    """kept index set bit-exact against the C restatement of nms.cu (+1 IoU, strict >)"""
+    g = torch.Generator().manual_seed(n)
+    ctr = torch.rand((n, 2), generator=g) * 300
+    wh = torch.rand((n, 2), generator=g) * 120 + 4
+    dets = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    scores = torch.rand((n,), generator=g)
+    want = cref.nms(dets, scores, thresh)
+    got = ext.nms(dets.to(device), scores.to(device), thresh)
+    assert got.is_cuda and got.dtype == torch.int64
+    assert torch.equal(got.cpu(), want)
+    assert 1 <= len(want) <= n
+
+
+def test_nms_known_answers(device):
+    # identical boxes: only the best-scored survives; disjoint boxes: all survive
+    same = torch.tensor([[10., 10., 50., 50.]]).repeat(5, 1)
+    sc = torch.tensor([0.1, 0.9, 0.5, 0.3, 0.7])
+    assert ext.nms(same.to(device), sc.to(device), 0.5).tolist() == [1]
+    apart = torch.tensor([[0., 0., 9., 9.], [20., 0., 29., 9.], [0., 20., 9., 29.]])
+    assert ext.nms(apart.to(device), sc[:3].to(device), 0.5).tolist() == [0, 1, 2]
+    # "+1" convention: boxes [0,9] and [5,14] overlap 5 px of 10 -> IoU = 50/(100+100-50) = 1/3
+    pair = torch.tensor([[0., 0., 9., 9.], [5., 0., 14., 9.]])
+    assert ext.nms(pair.to(device), sc[:2].to(device), 0.34).tolist() == [0, 1]
+    assert ext.nms(pair.to(device), sc[:2].to(device), 0.33).tolist() == [1]
+    empty = ext.nms(torch.zeros((0, 4), device=device), torch.zeros((0,), device=device), 0.5)
+    assert empty.numel() == 0 and not empty.is_cuda          # the reference's CPU-empty quirk

@@ -156,3 +156,14 @@ def test_extreme_utils_known_answers():
     w_, ind = cref.calculate_wnp(torch.tensor([[[2, 1]]]), torch.tensor([[[0, 2]]]), 4)
     assert w_.flatten().tolist() == [0.0, 0.5, 0.0, 0.0]
     assert ind[0, 0].tolist() == [[0, 1], [0, 1], [1, 0], [0, 0]]
+
+
+def test_nms_oracle_known_answers():
+    """C restatement of nms.cu on hand-computed cases ("+1" IoU, strict >, result ascending)."""
+    sc = torch.tensor([0.1, 0.9, 0.5, 0.3, 0.7])
+    same = torch.tensor([[10., 10., 50., 50.]]).repeat(5, 1)
+    assert cref.nms(same, sc, 0.5).tolist() == [1]
+    pair = torch.tensor([[0., 0., 9., 9.], [5., 0., 14., 9.]])
+    assert cref.nms(pair, sc[:2], 0.34).tolist() == [0, 1]       # IoU = 50 / 150
+    assert cref.nms(pair, sc[:2], 0.33).tolist() == [1]
+    assert cref.nms(torch.zeros((0, 4)), torch.zeros((0,)), 0.5).numel() == 0
