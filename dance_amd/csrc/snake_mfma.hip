@@ -378,9 +378,6 @@ int pick_rt(int v) { return v <= 64 ? 2 : (v <= 128 ? 4 : (v <= 224 ? 7 : 8)); }
 // channels per LDS chunk: as many as fit 64 KiB (two workgroups per CU), multiple of 16
 int pick_ck(int v, int cin_pad)
 {
-    static const int forced = getenv("DANCE_DEBUG_CK") ? atoi(getenv("DANCE_DEBUG_CK")) : 0;
-    if (forced > 0)
-        return forced < cin_pad ? forced : cin_pad;
     int ck = (16384 / v) & ~15;
     ck = ck > 256 ? 256 : ck;
     return ck < cin_pad ? ck : cin_pad;
