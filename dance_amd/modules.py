@@ -97,6 +97,15 @@ def _reference_init(module):
                 nn.init.constant_(m.bias, 0)
 
 
+def _image_slices(counts):
+    """contiguous per-image ranges of a batch laid out image by image"""
+    out, start = [], 0
+    for c in counts:
+        out.append(slice(start, start + int(c)))
+        start += int(c)
+    return out
+
+
 class _SnakeHeadBase(nn.Module):
     def _pack(self, names):
         """(Re)pack the deformers for the kernels when parameters changed or moved."""
@@ -284,8 +293,14 @@ class RefineNet(_SnakeHeadBase):
         preds = self.deform(features, locations, image_idx, image_sizes, whs)
         # predict_postprocess, snake_head.py:2399-2445
         results = []
-        for i, inst in enumerate(pred_instances):
-            sel = image_idx == i
+        # contours are laid out image by image (the samplers concatenate per image): plain
+        # slices instead of the reference's `image_idx == i` masks, which cost a device
+        # synchronisation per image
+        if self.initial == "octagon":
+            counts = [len(x.ext_points.tensor) if x.has("ext_points") else 0 for x in pred_instances]
+        else:
+            counts = [len(x.pred_boxes.tensor) for x in pred_instances]
+        for inst, sel in zip(pred_instances, _image_slices(counts)):
             inst.pred_polys = self.polygon_cls(preds[-1][sel])
             path = [locations[sel]] + [p[sel] for p in preds if p.size(1) == self.num_sampling]
             inst.pred_path = torch.stack(path, dim=1)
@@ -370,11 +385,12 @@ class DsnakeHead(_SnakeHeadBase):
         exts = pred_exts.clone()
         exts[..., 0] = torch.clamp(exts[..., 0], min=0, max=w - 1)               # :800-805
         exts[..., 1] = torch.clamp(exts[..., 1], min=0, max=h - 1)
-        for i, inst in enumerate(pred_instances):
+        slices = _image_slices(len(b) for b in boxes)
+        for inst, sel in zip(pred_instances, slices):
             if not inst.has("ext_points"):
-                inst.ext_points = self.extreme_cls(exts[image_idx == i])
+                inst.ext_points = self.extreme_cls(exts[sel])
             else:                                    # GT extreme points given (:811-817)
-                exts[image_idx == i] = inst.ext_points.tensor
+                exts[sel] = inst.ext_points.tensor
         locations, _ = ops.uniform_upsample(exts.contiguous(), self.num_sampling, kind=ops.POLY_OCTAGON)
         preds, cur = [], locations
         for i in range(len(self.num_iter)):
@@ -382,8 +398,7 @@ class DsnakeHead(_SnakeHeadBase):
                            clip_max=(0.0, 0.0))
             preds.append(cur)
         results = []
-        for i, inst in enumerate(pred_instances):                                 # :857-877
-            sel = image_idx == i
+        for inst, sel in zip(pred_instances, slices):                             # :857-877
             inst.pred_polys = self.polygon_cls(preds[-1][sel])
             if self.visualize_path:
                 path = [locations[sel]] + [p[sel] for p in preds[:-1]]
