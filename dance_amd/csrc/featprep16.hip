@@ -7,9 +7,9 @@
 // fp32 accumulation (fp32-level accuracy at the 16-bit matrix rate).
 //
 //   k_nchw_to_p16img : NCHW fp32 -> "P16 image" [b][plane hi/lo][c/8][y][x][8] fp16
-//   k_conv3x3_16     : implicit GEMM, one workgroup = 2 rows x 64 pixels x 128 output channels
+//   k_conv3x3_16     : implicit GEMM, one workgroup = 4 rows x 32 pixels x 128 output channels
 //                      (4 waves x 32 channels, 16x16x32 MFMA tiles).  Input chunks of 32
-//                      channels with their 1-pixel halo (4 rows x 66 pixels) are double-buffered
+//                      channels with their 1-pixel halo (6 rows x 34 pixels) are double-buffered
 //                      in LDS; the 9 taps are immediate offsets into that image.  Output: the
 //                      raw convolution, fp32, channel-blocked [b][c/16][y][x][16] (every wave
 //                      store is 1 KB contiguous), plus per-(image, group) sum / sum of squares
@@ -59,11 +59,14 @@ struct Conv2dArgs {
     int h, w_, cin, cout, group_ch;
 };
 
-constexpr int C2_HR = 4, C2_PW = 66, C2_CB = 4;
+constexpr int C2_TR = 4, C2_TC = 32;                       // output tile: rows x columns (128 pixels)
+constexpr int C2_HR = C2_TR + 2, C2_PW = C2_TC + 2, C2_CB = 4;
 constexpr int C2_PLANE = C2_CB * C2_HR * C2_PW * 16;        // bytes per plane of a chunk image
 constexpr int C2_BYTES = 2 * C2_PLANE;                      // 33,792
 constexpr int C2_WORDS = C2_BYTES / 16;                     // 2112
-constexpr int C2_NSTG = 9;                                  // staged 16-B loads per thread and chunk
+constexpr int C2_NSTG = (C2_WORDS + 255) / 256;              // staged 16-B loads per thread and chunk (<= 9 taps)
+static_assert(C2_NSTG <= 9, "one staged load per tap");
+constexpr int C2_TPR = C2_TC / 16;                          // 16-pixel column tiles per tile row
 
 __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
 {
@@ -71,13 +74,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c16 = lane & 15, q4 = lane >> 4;
-    const int tiles_x = (a.w_ + 63) >> 6, rows2 = (a.h + 1) >> 1;
+    const int tiles_x = (a.w_ + C2_TC - 1) / C2_TC, rows2 = (a.h + C2_TR - 1) / C2_TR;
     // the output-channel tile is the fast grid index: the workgroups that share an input
     // tile run together and the second one finds it in L2
     const int mtiles = a.cout >> 7;
     const int mt = blockIdx.x % mtiles, bid = blockIdx.x / mtiles;
     const int tx = bid % tiles_x, ty = (bid / tiles_x) % rows2, b = bid / (tiles_x * rows2);
-    const int x0 = tx * 64, y0 = ty * 2;
+    const int x0 = tx * C2_TC, y0 = ty * C2_TR;
     const int o0 = mt * 128 + wave * 32;
     const long long hw = (long long)a.h * a.w_;
     const int cbt = a.cin >> 3, nch = a.cin >> 5;
@@ -148,11 +151,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
         const char *wchunk = wbase + (long long)chunk * C2_CB * wbs_b;
         const unsigned pb = lanebase + cur;
         h8 bh[4], bl[4];
-        // tile Q = tap * 8 + j: tap (ky, kx), j = (row j >> 2, columns 16 (j & 3) ..)
+        // tile Q = tap * 8 + j: tap (ky, kx), j = (row j / C2_TPR, columns 16 (j % C2_TPR) ..)
 #define C2_LOAD_B(Q)                                                                              \
     do {                                                                                          \
         constexpr int tap_ = (Q) / 8, j_ = (Q) % 8;                                               \
-        constexpr int imm_ = (((j_ >> 2) + tap_ / 3) * C2_PW + 16 * (j_ & 3) + tap_ % 3) * 16;    \
+        constexpr int imm_ = ((j_ / C2_TPR + tap_ / 3) * C2_PW + 16 * (j_ % C2_TPR) + tap_ % 3) * 16; \
         bh[(Q) % 4] = *reinterpret_cast<const h8 *>(xs + pb + imm_);                              \
         bl[(Q) % 4] = *reinterpret_cast<const h8 *>(xs + pb + imm_ + C2_PLANE);                   \
     } while (0)
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
                 else if (more)
                     C2_LOAD_A((tap + 2) % 3, wchunk + C2_CB * wbs_b + (tap + 2 - 9) * wts_b);
                 // one staged activation load per tap, issued after the weight prefetch
-                C2_STAGE(tap, ssrc);
+                if constexpr (tap < C2_NSTG)
+                    C2_STAGE(tap, ssrc);
             }
             if constexpr (q + 3 < 72)
                 C2_LOAD_B(q + 3);
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
 #undef C2_STAGE
 #undef C2_COMMIT
 
-    // epilogue: lane = pixel (row j >> 2, column 16 (j & 3) + c16), channels o0 + 16 i + 4 q4 .. + 3
+    // epilogue: lane = pixel (row j / C2_TPR, column 16 (j % C2_TPR) + c16), channels o0 + 16 i + 4 q4 .. + 3
     const int nblk = a.cout >> 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
         float *yb = a.y + (((long long)b * nblk + ((o0 >> 4) + i)) * hw) * 16 + 4 * q4;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int yy = y0 + (j >> 2), xx = x0 + 16 * (j & 3) + c16;
+            const int yy = y0 + j / C2_TPR, xx = x0 + 16 * (j % C2_TPR) + c16;
             if (yy < a.h && xx < a.w_) {
                 const f32x4 v = acc[i][j] * a.winv;
                 *reinterpret_cast<f32x4 *>(yb + ((long long)yy * a.w_ + xx) * 16) = v;
@@ -323,7 +327,7 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
     Conv2dArgs a;
     a.x = (const _Float16 *)x16; a.w = (const h8 *)w16; a.winv = w_inv_scale; a.y = y_blocked;
     a.stats = stats; a.h = h; a.w_ = w; a.cin = cin; a.cout = cout; a.group_ch = cout / groups;
-    const long long tiles = (long long)b * ((h + 1) / 2) * ((w + 63) / 64);
+    const long long tiles = (long long)b * ((h + C2_TR - 1) / C2_TR) * ((w + C2_TC - 1) / C2_TC);
     DANCE_REQUIRE(tiles * (cout / 128) < (1ll << 31));
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)b * groups, (hipStream_t)stream);
     if (e != hipSuccess)
