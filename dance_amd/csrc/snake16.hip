@@ -75,7 +75,7 @@ struct Geo {
 //                 (the place for staged activation loads)
 // AD weight buffers rotate (prefetch distance AD - 1 steps); NB vertex-tile (B) buffers rotate
 // over the flat tile sequence q = s * RT + rt (prefetch distance NB - 1 tiles).
-template <int RT, int OTW, int NST, int AD, int NB, typename Hook>
+template <int RT, int OTW, int NST, int AD, int NB, int TERMS, typename Hook>
 __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *xs, unsigned lds0, int v,
                                             const char *wchunk, unsigned wlane, long long wps_b,
                                             long long wts_b, long long wstep_b, int taps, int dilation,
@@ -99,7 +99,8 @@ __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *
         const char *pa_ = (PTR);                                                                  \
         _Pragma("unroll") for (int ot_ = 0; ot_ < OTW; ++ot_) {                                   \
             ah[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wlane + ot_ * 512);               \
-            al[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + ot_ * 512);       \
+            if constexpr (TERMS == 3)                                                             \
+                al[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + ot_ * 512);   \
         }                                                                                         \
     } while (0)
     // tile Q of the current tap (Q < NT) or of the next one (p[] of its vertex tile already
@@ -108,7 +109,8 @@ __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *
     do {                                                                                          \
         constexpr int q_ = (Q) % NT, s_ = q_ / RT, rt_ = q_ % RT;                                 \
         bh[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[rt_] + s_ * SSTEP);                   \
-        bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[rt_] + s_ * SSTEP + G::PLANE);        \
+        if constexpr (TERMS == 3)                                                                 \
+            bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[rt_] + s_ * SSTEP + G::PLANE);    \
         if (s_ == NST - 1) {                                                                      \
             const unsigned tpos_ = p[rt_] + d16;                                                  \
             p[rt_] = tpos_ >= lim ? tpos_ - v16 : tpos_;                                          \
@@ -137,12 +139,14 @@ __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *
             // keep the prefetch ahead of this tile's MFMAs (the scheduler otherwise sinks it
             // below them and the rotation collapses into load -> wait -> use)
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TERMS == 3) {
 #pragma unroll
-            for (int ot = 0; ot < OTW; ++ot)
-                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % AD][ot], bh[q % NB], acc[ot][rt], 0, 0, 0);
+                for (int ot = 0; ot < OTW; ++ot)
+                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % AD][ot], bh[q % NB], acc[ot][rt], 0, 0, 0);
 #pragma unroll
-            for (int ot = 0; ot < OTW; ++ot)
-                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bl[q % NB], acc[ot][rt], 0, 0, 0);
+                for (int ot = 0; ot < OTW; ++ot)
+                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bl[q % NB], acc[ot][rt], 0, 0, 0);
+            }
 #pragma unroll
             for (int ot = 0; ot < OTW; ++ot)
                 acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bh[q % NB], acc[ot][rt], 0, 0, 0);
@@ -162,7 +166,7 @@ __device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *
 // NST = steps of 32 channels per chunk; wlane = (q4 * cout + c16) * 16; wstep_b = 4 blocks.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int RT, int NST, int AD, int NB, typename Hook>
+template <int RT, int NST, int AD, int NB, int TERMS, typename Hook>
 __device__ __forceinline__ void mfma16_core_s(f32x4 (&acc)[2][2 * RT], const char *xs, unsigned lds0, int v,
                                               const char *wchunk, unsigned wlane, long long wps_b,
                                               long long wts_b, long long wstep_b, int taps, int dilation,
@@ -186,14 +190,16 @@ __device__ __forceinline__ void mfma16_core_s(f32x4 (&acc)[2][2 * RT], const cha
         const char *pa_ = (PTR);                                                                  \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                        \
             ah[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wlane + i_ * 256);                 \
-            al[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + i_ * 256);         \
+            if constexpr (TERMS == 3)                                                             \
+                al[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + i_ * 256);     \
         }                                                                                         \
     } while (0)
 #define DANCE_LOAD_B(Q)                                                                           \
     do {                                                                                          \
         constexpr int q_ = (Q) % NT, s_ = q_ / CT, j_ = q_ % CT;                                  \
         bh[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[j_] + s_ * SSTEP);                    \
-        bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[j_] + s_ * SSTEP + G::PLANE);         \
+        if constexpr (TERMS == 3)                                                                 \
+            bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[j_] + s_ * SSTEP + G::PLANE);     \
         if (s_ == NST - 1) {                                                                      \
             const unsigned tpos_ = p[j_] + d16;                                                   \
             p[j_] = tpos_ >= lim ? tpos_ - v16 : tpos_;                                           \
@@ -220,10 +226,12 @@ __device__ __forceinline__ void mfma16_core_s(f32x4 (&acc)[2][2 * RT], const cha
             }
             DANCE_LOAD_B(q + DB);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][0], bh[q % NB], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][1], bh[q % NB], acc[1][j], 0, 0, 0);
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][0], bl[q % NB], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][1], bl[q % NB], acc[1][j], 0, 0, 0);
+            if constexpr (TERMS == 3) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][0], bh[q % NB], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][1], bh[q % NB], acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][0], bl[q % NB], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][1], bl[q % NB], acc[1][j], 0, 0, 0);
+            }
             acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][0], bh[q % NB], acc[0][j], 0, 0, 0);
             acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][1], bh[q % NB], acc[1][j], 0, 0, 0);
         });
@@ -300,7 +308,7 @@ __device__ __forceinline__ float relu_nan(float x) { return x > 0.0f ? x : (x !=
 // than n, of the workgroup's next contour -- is staged into registers and committed to the
 // other buffer at the chunk boundary.  With two chunks per contour (128 channels) both stay
 // resident, and the residual is read back from LDS in the epilogue.
-template <int RT>
+template <int RT, int TERMS>
 __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
 {
     constexpr int CBC = RT <= 4 ? 8 : 4, NST = CBC / 2, AD = NST % 4 == 0 ? 4 : 2, NW = 4;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
                 auto hook = [&](int s) __attribute__((always_inline)) {
                     stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
                 };
-                mfma16_core<RT, 1, NST, AD, NB>(acc, xs, cur, v,
+                mfma16_core<RT, 1, NST, AD, NB, TERMS>(acc, xs, cur, v,
                                             reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * a.cout + o0) * 16,
                                             wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, hook);
             } else {
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_conv16(Conv16Args a, int n)
 // than n, of the workgroup's next contour -- is staged into registers and committed to the
 // other buffer at the chunk boundary.  With two chunks per contour (128 channels) both stay
 // resident, and the residual is read back from LDS in the epilogue.
-template <int RT>
+template <int RT, int TERMS>
 __global__ __launch_bounds__(256, 2) void k_conv16s(Conv16Args a, int n)
 {
     static_assert(RT <= 4, "larger rings use k_conv16");
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void k_conv16s(Conv16Args a, int n)
                 auto hook = [&](int s) __attribute__((always_inline)) {
                     stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
                 };
-                mfma16_core_s<RT, NST, AD, NB>(acc, xs, cur, v,
+                mfma16_core_s<RT, NST, AD, NB, TERMS>(acc, xs, cur, v,
                                                reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * a.cout + o0) * 16,
                                                wlane, wps_b, wts_b, 4 * wbs_b, a.taps, a.dilation, c16, q4, hook);
             } else {
@@ -616,7 +624,7 @@ struct Fuse16Args {
     int v;
 };
 
-template <int RT>
+template <int RT, int TERMS>
 __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
 {
     constexpr int CBC = 8, NST = 4, AD = 2, NW = 8, NCH = 1024 / (CBC * 8);
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
             auto hook = [&](int s) __attribute__((always_inline)) {
                 stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
             };
-            mfma16_core<RT, 2, NST, AD, 2>(acc, xs, cur, v,
+            mfma16_core<RT, 2, NST, AD, 2, TERMS>(acc, xs, cur, v,
                                         reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * 512 + o0) * 16,
                                         wlane, wts_b, wts_b, 2 * wbs_b, 1, 1, r, h, hook);
             __syncthreads();
@@ -738,7 +746,7 @@ struct Gather16Args {
     int b, hf, wf, c, reflection, deloc;
 };
 
-template <int RT>
+template <int RT, int TERMS>
 __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16Args g)
 {
     constexpr int CBC = 8;                                      // 64 channels per chunk
@@ -828,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
             *reinterpret_cast<h4 *>(d + G::PLANE) = lo;
         }
         __syncthreads();
-        mfma16_core<RT, 1, 4, 4, 4>(acc, xs, 0, v,
+        mfma16_core<RT, 1, 4, 4, 4, TERMS>(acc, xs, 0, v,
                                  reinterpret_cast<const char *>(a.w) + ((long long)(c0 >> 3) * a.cout + o0) * 16,
                                  wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
     }
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
             *reinterpret_cast<h8 *>(xs + GD::PLANE + (blk * GD::VP + vi) * 16) = lo;
         }
         __syncthreads();
-        mfma16_core<RT, 1, 2, 2, 2>(acc, xs, 0, v,
+        mfma16_core<RT, 1, 2, 2, 2, TERMS>(acc, xs, 0, v,
                                  reinterpret_cast<const char *>(a.w) + ((long long)(g.c >> 3) * a.cout + o0) * 16,
                                  wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
     }
@@ -892,15 +900,40 @@ int big_lds(K kernel, size_t bytes, const char *fn)
     return e == hipSuccess ? 0 : dance::fail((int)e, fn, hipGetErrorString(e));
 }
 
-#define LAUNCH_RT(KERNEL, rt, grid, block, lds, s, fn, ...)                                  \
+#define LAUNCH_ONE(KERNEL, RTV, terms, grid, block, lds, s, fn, ...)                          \
+    do {                                                                                      \
+        if ((terms) == 1) {                                                                   \
+            rc_ = big_lds(KERNEL<RTV, 1>, lds, fn);                                           \
+            if (!rc_)                                                                         \
+                hipLaunchKernelGGL((KERNEL<RTV, 1>), grid, block, lds, s, __VA_ARGS__);       \
+        } else {                                                                              \
+            rc_ = big_lds(KERNEL<RTV, 3>, lds, fn);                                           \
+            if (!rc_)                                                                         \
+                hipLaunchKernelGGL((KERNEL<RTV, 3>), grid, block, lds, s, __VA_ARGS__);       \
+        }                                                                                     \
+    } while (0)
+
+#define LAUNCH_RT(KERNEL, rt, terms, grid, block, lds, s, fn, ...)                           \
     do {                                                                                      \
         int rc_ = 0;                                                                          \
         switch (rt) {                                                                         \
-        case 2: rc_ = big_lds(KERNEL<2>, lds, fn); if (!rc_) hipLaunchKernelGGL(KERNEL<2>, grid, block, lds, s, __VA_ARGS__); break; \
-        case 4: rc_ = big_lds(KERNEL<4>, lds, fn); if (!rc_) hipLaunchKernelGGL(KERNEL<4>, grid, block, lds, s, __VA_ARGS__); break; \
-        case 7: rc_ = big_lds(KERNEL<7>, lds, fn); if (!rc_) hipLaunchKernelGGL(KERNEL<7>, grid, block, lds, s, __VA_ARGS__); break; \
-        default: rc_ = big_lds(KERNEL<8>, lds, fn); if (!rc_) hipLaunchKernelGGL(KERNEL<8>, grid, block, lds, s, __VA_ARGS__); break; \
+        case 2: LAUNCH_ONE(KERNEL, 2, terms, grid, block, lds, s, fn, __VA_ARGS__); break;    \
+        case 4: LAUNCH_ONE(KERNEL, 4, terms, grid, block, lds, s, fn, __VA_ARGS__); break;    \
+        case 7: LAUNCH_ONE(KERNEL, 7, terms, grid, block, lds, s, fn, __VA_ARGS__); break;    \
+        default: LAUNCH_ONE(KERNEL, 8, terms, grid, block, lds, s, fn, __VA_ARGS__); break;   \
         }                                                                                     \
+        if (rc_)                                                                              \
+            return rc_;                                                                       \
+    } while (0)
+
+// rings of at most 128 vertices only (RT 2 / 4)
+#define LAUNCH_RT24(KERNEL, rt, terms, grid, block, lds, s, fn, ...)                         \
+    do {                                                                                      \
+        int rc_ = 0;                                                                          \
+        if ((rt) == 2)                                                                        \
+            LAUNCH_ONE(KERNEL, 2, terms, grid, block, lds, s, fn, __VA_ARGS__);               \
+        else                                                                                  \
+            LAUNCH_ONE(KERNEL, 4, terms, grid, block, lds, s, fn, __VA_ARGS__);               \
         if (rc_)                                                                              \
             return rc_;                                                                       \
     } while (0)
@@ -912,8 +945,9 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
                             const float *shift, const float *rowinit, int residual, int relu,
                             int maxv, void *y16, int64_t y_stride, int64_t y_slot_stride, float *y_f32,
                             int64_t yf_stride, int n, int v, int cin, int cout, int taps, int dilation,
-                            void *stream)
+                            int mfma_terms, void *stream)
 {
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
     DANCE_REQUIRE(cin >= 32 && cin % 32 == 0 && (cin <= 128 || cin % 128 == 0));
     DANCE_REQUIRE(cout >= 32 && cout % 32 == 0);
@@ -946,29 +980,19 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
     // chip holds a higher clock on that shape); DANCE_MFMA_SHAPE=32 selects the 32x32x16 kernel
     static const int shape16 = env_int("DANCE_MFMA_SHAPE", 16) == 16;
     if (shape16 && rt <= 4) {
-        int rc = 0;
-        if (rt == 2) {
-            rc = big_lds(k_conv16s<2>, lds, __func__);
-            if (!rc)
-                hipLaunchKernelGGL(k_conv16s<2>, grid, dim3(256), lds, (hipStream_t)stream, a, n);
-        } else {
-            rc = big_lds(k_conv16s<4>, lds, __func__);
-            if (!rc)
-                hipLaunchKernelGGL(k_conv16s<4>, grid, dim3(256), lds, (hipStream_t)stream, a, n);
-        }
-        if (rc)
-            return rc;
+        LAUNCH_RT24(k_conv16s, rt, mfma_terms, grid, dim3(256), lds, (hipStream_t)stream, "dance_conv16", a, n);
         return launch_check(__func__);
     }
-    LAUNCH_RT(k_conv16, rt, grid, dim3(256), lds, (hipStream_t)stream, "dance_conv16", a, n);
+    LAUNCH_RT(k_conv16, rt, mfma_terms, grid, dim3(256), lds, (hipStream_t)stream, "dance_conv16", a, n);
     return launch_check(__func__);
 }
 
 extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
                             const float *bias_scaled, float w_inv_scale, const float *wg,
                             const float *pred_bias, void *y16, int64_t y_stride, int64_t y_slot_stride,
-                            int n, int v, void *stream)
+                            int n, int v, int mfma_terms, void *stream)
 {
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
     if (n == 0)
         return 0;
@@ -982,18 +1006,7 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // two 64-channel chunk images
     static const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
     dim3 grid(slots > 0 && slots < n ? slots : n);
-    int rc = 0;
-    if (rt == 2) {
-        rc = big_lds(k_fuse16<2>, lds, __func__);
-        if (!rc)
-            hipLaunchKernelGGL(k_fuse16<2>, grid, dim3(512), lds, (hipStream_t)stream, a, n);
-    } else {
-        rc = big_lds(k_fuse16<4>, lds, __func__);
-        if (!rc)
-            hipLaunchKernelGGL(k_fuse16<4>, grid, dim3(512), lds, (hipStream_t)stream, a, n);
-    }
-    if (rc)
-        return rc;
+    LAUNCH_RT24(k_fuse16, rt, mfma_terms, grid, dim3(512), lds, (hipStream_t)stream, "dance_fuse16", a, n);
     return launch_check(__func__);
 }
 
@@ -1001,8 +1014,9 @@ extern "C" int dance_gather_head16(const float *feat, const float *att, const fl
                                    const int32_t *image_idx, const void *w16, const float *bias_scaled,
                                    float w_inv_scale, const float *scale, const float *shift, void *y16,
                                    int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf,
-                                   int c, int padding_mode, int deloc_type, void *stream)
+                                   int c, int padding_mode, int deloc_type, int mfma_terms, void *stream)
 {
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
     DANCE_REQUIRE(b >= 1 && hf >= 1 && wf >= 1 && (long long)hf * wf < (1ll << 30));
     DANCE_REQUIRE(c >= 64 && c % 64 == 0);
@@ -1023,7 +1037,7 @@ extern "C" int dance_gather_head16(const float *feat, const float *att, const fl
     g.deloc = deloc_type;
     const int rt = pick_rt16(v);
     const size_t lds = (size_t)2 * 8 * (rt * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
-    LAUNCH_RT(k_gather_head16, rt, dim3(n), dim3(256), lds, (hipStream_t)stream,
+    LAUNCH_RT(k_gather_head16, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream,
               "dance_gather_head16", a, g);
     return launch_check(__func__);
 }

@@ -635,10 +635,11 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
                                     float *out, void *workspace, int64_t workspace_bytes, int n, int v,
                                     int b, int hf, int wf, int padding_mode, int deloc_type,
                                     int individual_scale, int use_att, int clip_first,
-                                    float clip_x_max, float clip_y_max, void **stage_events_host,
-                                    void *stream)
+                                    float clip_x_max, float clip_y_max, int mfma_terms,
+                                    void **stage_events_host, void *stream)
 {
     DANCE_REQUIRE(net != nullptr && n >= 0);
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     if (n == 0)
         return 0;
     DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr);
@@ -671,19 +672,19 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
         DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
                                       net->head_winv, net->head_scale, net->head_shift, state, sstride,
                                       use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
-                                      deloc_type, stream));
+                                      deloc_type, mfma_terms, stream));
     }
     DANCE_TRY(mark());
     for (int i = 0; i < 7; ++i) {
         DANCE_TRY(dance_conv16(state + i * slot, sstride, slot, net->res_w[i], net->res_bs[i],
                                net->res_winv[i], net->res_scale[i], net->res_shift[i], nullptr, 1, 1, 0,
                                state + (i + 1) * slot, sstride, slot, nullptr, 0, n, v, 128, 128, 9,
-                               net->dilation[i], stream));
+                               net->dilation[i], mfma_terms, stream));
         DANCE_TRY(mark());
     }
     if (v <= 128) {
         DANCE_TRY(dance_fuse16(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv,
-                               net->pred0_wg, net->pred0_b, p1, pstride, slot, n, v, stream));
+                               net->pred0_wg, net->pred0_b, p1, pstride, slot, n, v, mfma_terms, stream));
         DANCE_TRY(mark());
         DANCE_TRY(mark());      // row constant: inside the fused kernel
         DANCE_TRY(mark());      // prediction[0]: inside the fused kernel
@@ -693,18 +694,18 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
         DANCE_REQUIRE(net->fuse_w_split != nullptr && net->pred0_w_split != nullptr);
         DANCE_TRY(dance_conv16(state, sstride, slot, net->fuse_w_split, net->fuse_bs, net->fuse_winv,
                                nullptr, nullptr, nullptr, 0, 0, 1, nullptr, 0, 0, w.gmax, 0, n, v,
-                               1024, 256, 1, 1, stream));
+                               1024, 256, 1, 1, mfma_terms, stream));
         DANCE_TRY(mark());
         DANCE_TRY(dance_row_constant(w.gmax, net->pred0_wg, net->pred0_b, w.h, n, 256, 256, stream));
         DANCE_TRY(mark());
         DANCE_TRY(dance_conv16(state, sstride, slot, net->pred0_w_split, nullptr, net->fuse_winv,
                                nullptr, nullptr, w.h, 0, 1, 0, p1, pstride, slot, nullptr, 0, n, v,
-                               1024, 256, 1, 1, stream));
+                               1024, 256, 1, 1, mfma_terms, stream));
         DANCE_TRY(mark());
     }
     DANCE_TRY(dance_conv16(p1, pstride, slot, net->pred1_w, net->pred1_bs, net->pred1_winv, nullptr,
                            nullptr, nullptr, 0, 1, 0, nullptr, 0, 0, w.p2, 64ll * v, n, v, 256, 64, 1,
-                           1, stream));
+                           1, mfma_terms, stream));
     DANCE_TRY(mark());
     DANCE_TRY(dance_offset_update(w.p2, 64ll * v, net->pred2_w, net->pred2_b, loc,
                                   individual_scale ? whs : nullptr, use_att ? w.att_s : nullptr, out,

@@ -163,7 +163,7 @@ def from_p16(p):
 
 
 def conv16(x16, w16, scale_pow2, bias, *, cin, cout, v, dilation=1, bn_scale=None, bn_shift=None,
-           residual=False, relu=False, rowinit=None, maxv=False, out_f32=False):
+           residual=False, relu=False, rowinit=None, maxv=False, out_f32=False, mfma_terms=3):
     """dance_conv16 on a P16 block (N, slots, 2, 16, V, 8); returns P16 (N, cout/128 slots, ...)
     or fp32 (N, cout, V) / (N, cout) with out_f32 / maxv."""
     _need_gpu(x16, w16)
@@ -183,7 +183,7 @@ def conv16(x16, w16, scale_pow2, bias, *, cin, cout, v, dilation=1, bn_scale=Non
         check(lib().dance_conv16(ptr(x16), x16.stride(0), slot, ptr(w16), ptr(bias_s), 1.0 / scale_pow2,
                                  ptr(bn_scale), ptr(bn_shift), ptr(rowinit), int(residual), int(relu),
                                  int(maxv), ptr(y16), 0 if y16 is None else y16.stride(0), slot, ptr(yf),
-                                 yfs, n, v, cin, cout, taps, dilation, current_stream()), "conv16")
+                                 yfs, n, v, cin, cout, taps, dilation, mfma_terms, current_stream()), "conv16")
     return yf if y16 is None else y16
 
 

@@ -147,12 +147,14 @@ class ContourDeformer:
 
     def __init__(self, nets, padding="reflection", de_loc_type="derange", individual_scale=True,
                  attention=True, fused_head=True, precision=None):
-        """precision: "fp16x3" -- split-half operands, three f16 MFMAs per product, fp32
+        """precision: "fp16" -- APPROXIMATE: plain fp16 operands (one MFMA per product, fp32
+        accumulate), ~1e-2 coordinate error, outside the 1e-4 parity bar; never the default.
+        "fp16x3" -- split-half operands, three f16 MFMAs per product, fp32
         accumulation (fp32-level accuracy, the default); "fp32" -- exact fp32 MFMA."""
         if precision is None:
             precision = os.environ.get("DANCE_PRECISION", "fp16x3")
-        if precision not in ("fp16x3", "fp32"):
-            raise ValueError("precision must be 'fp16x3' or 'fp32'")
+        if precision not in ("fp16x3", "fp32", "fp16"):
+            raise ValueError("precision must be 'fp16x3', 'fp32' or 'fp16'")
         self.precision = precision
         self.nets = list(nets)
         self._padding_name, self._deloc_name, self._side = padding, de_loc_type, None
@@ -233,7 +235,9 @@ class ContourDeformer:
                 nb = min(chunk, n - n0)
                 args16 = ()
                 fn = lib().dance_snake_evolve
-                fast = self.precision == "fp16x3" and c % 64 == 0
+                fast = self.precision in ("fp16x3", "fp16") and c % 64 == 0
+                if self.precision == "fp16" and not fast:
+                    raise RuntimeError("precision 'fp16' needs feature channels % 64 == 0")
                 if fast:
                     fn = lib().dance_snake_evolve16
                     args16 = (ctypes.byref(net.struct16),)
@@ -244,7 +248,8 @@ class ContourDeformer:
                     ptr(x_in[n0:]) if x_in is not None else None, ptr(out[n0:]), ptr(ws), need,
                     nb, v, b, hf, wf, self.padding, self.deloc, int(self.individual_scale),
                     int(use_att), int(clip_first and n0 == 0), float(clip_max[0]), float(clip_max[1]),
-                    *(() if fast else (int(self.fused_head),)), ev, stream), "snake_evolve")
+                    *((1 if self.precision == "fp16" else 3,) if fast else (int(self.fused_head),)),
+                    ev, stream), "snake_evolve")
         return out
 
     def deform(self, features, init_contours, image_idx, image_sizes, whs, layout="nchw",

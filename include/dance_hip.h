@@ -230,7 +230,11 @@ int dance_snake_evolve(const dance_snake_net *net_host, const float *feat, const
  * P16 block of C channels (C % 128 == 0 or C <= 128; always slots of 128):
  *   [slot][plane hi/lo][c/8][v][8] halfs, slot stride given by the caller.
  * Packed weights w16: [plane][tap][cin_pad16/8][cout][8] halfs of (w * 2^s), with
- * bias_scaled = bias * 2^s and w_inv_scale = 2^-s (dance_amd.ops.pack_conv_weight16).       */
+ * bias_scaled = bias * 2^s and w_inv_scale = 2^-s (dance_amd.ops.pack_conv_weight16).
+ *
+ * mfma_terms: 3 = the parity mode described above; 1 = only the hi x hi product (plain fp16
+ * operands, fp32 accumulate: one third of the MFMAs, ~1e-2 coordinate error -- the
+ * approximate "half precision" variant of BASELINE config 2, never the default).            */
 
 /* Same op as dance_circconv on P16 input.  Output either P16 (y16) or fp32 channel-major
  * (y_f32); residual != 0 adds the input itself (needs cin == cout <= 128); rowinit (n,cout)
@@ -241,7 +245,7 @@ int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stride, const v
                  const float *shift, const float *rowinit, int residual, int relu, int maxv,
                  void *y16, int64_t y_stride, int64_t y_slot_stride, float *y_f32,
                  int64_t yf_stride, int n, int v, int cin, int cout, int taps, int dilation,
-                 void *stream);
+                 int mfma_terms, void *stream);
 
 /* fusion Conv1d + max over the ring + row constant + prediction[0] in one pass over the
  * (n, 1024, v) P16 state.  w16 packs fusion.weight (outputs 0..255) and the 1024 state
@@ -253,7 +257,7 @@ int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stride, const v
 int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
                  const float *bias_scaled, float w_inv_scale, const float *wg,
                  const float *pred_bias, void *y16, int64_t y_stride, int64_t y_slot_stride, int n,
-                 int v, void *stream);
+                 int v, int mfma_terms, void *stream);
 
 /* Fused gather + de_location + head SnakeBlock writing slot 0 of a P16 block
  * (as dance_gather_circconv_head; c % 64 == 0). */
@@ -261,7 +265,7 @@ int dance_gather_head16(const float *feat, const float *att, const float *loc,
                         const int32_t *image_idx, const void *w16, const float *bias_scaled,
                         float w_inv_scale, const float *scale, const float *shift, void *y16,
                         int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf, int c,
-                        int padding_mode, int deloc_type, void *stream);
+                        int padding_mode, int deloc_type, int mfma_terms, void *stream);
 
 typedef struct dance_snake_net16 {
     const void *head_w;  const float *head_bs, *head_scale, *head_shift;
@@ -284,7 +288,7 @@ int dance_snake_evolve16(const dance_snake_net16 *net_host, const dance_snake_ne
                          const int32_t *image_idx, const float *whs, const float *x_in, float *out,
                          void *workspace, int64_t workspace_bytes, int n, int v, int b, int hf,
                          int wf, int padding_mode, int deloc_type, int individual_scale, int use_att,
-                         int clip_first, float clip_x_max, float clip_y_max,
+                         int clip_first, float clip_x_max, float clip_y_max, int mfma_terms,
                          void **stage_events_host, void *stream);
 
 #ifdef __cplusplus

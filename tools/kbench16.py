@@ -17,7 +17,7 @@ def run(n, v, cin, cout, taps, dil, reps=3 if os.environ.get('DANCE_DEBUG_STAMPS
     def f():
         check(lib().dance_conv16(ptr(x), x.stride(0), slot, ptr(w), ptr(b), 1.0 / s, ptr(sc), ptr(sh), None,
                                  int(res), 1, 0, ptr(y), y.stride(0), slot, None, 0, n, v, cin, cout, taps, dil,
-                                 current_stream()), "conv16")
+                                 int(os.environ.get('KB_TERMS', '3')), current_stream()), "conv16")
     for _ in range(2):
         f()
     torch.cuda.synchronize()
