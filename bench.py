@@ -130,12 +130,20 @@ def main():
     sizes = [(h, w)] * b
     del g
 
-    events = [[[torch.cuda.Event(enable_timing=True) for _ in range(EVOLVE_EVENTS)]
+    # Timed steps carry three events per iteration only (an event record costs ~4 us of stream
+    # time): before the head kernel, after it, after the last residual block -- the gather
+    # figure and the roofline of the dominant kernel.  The full per-stage breakdown comes from
+    # an instrumented pass after the timed region.
+    TIMED = (0, 1, 8)
+    events = [[[torch.cuda.Event(enable_timing=True) if i in TIMED else None for i in range(EVOLVE_EVENTS)]
                for _ in range(ITERS)] for _ in range(args.steps)]
-    for step_ev in events:
+    events_full = [[[torch.cuda.Event(enable_timing=True) for _ in range(EVOLVE_EVENTS)]
+                    for _ in range(ITERS)] for _ in range(args.steps)]
+    for step_ev in events + events_full:
         for it_ev in step_ev:
             for e in it_ev:
-                e.record()                                   # creates the handle
+                if e is not None:
+                    e.record()                               # creates the handle
     layout_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                  for _ in range(args.steps)]
     pre = deformer.prepare_features(feats) if args.layout == "nhwc" else None
@@ -172,13 +180,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (world * n, v, 2) and bool(torch.isfinite(out).all())
-    if args.streams > 1 and rank == 0:
-        # per-stage events cannot be read off overlapping streams: one instrumented
-        # single-stream pass after the timed region fills the per-kernel durations
+    if rank == 0:
+        # instrumented single-stream pass (every stage boundary); with --streams > 1 it also
+        # supplies the three timed events, which cannot be read off overlapping streams
         for k in range(args.steps):
             f = deformer.prepare_features(feats) if pre is None else pre
-            deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", stage_events=events[k])
+            deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", stage_events=events_full[k])
         torch.cuda.synchronize()
+        if args.streams > 1:
+            events = events_full
 
     # the gather stage on its own (k_gather: 4 taps x 257 channels per vertex -> (N, 258, V)),
     # outside the timed region: the HBM-bound form of the stage that k_gather_head* fuses
@@ -252,14 +262,19 @@ def main():
         stage_ms = [0.0] * len(STAGE_NAMES)
         for k in range(args.steps):
             for it in range(ITERS):
-                ev = events[k][it]
+                ev = events_full[k][it]
                 for s in range(len(STAGE_NAMES)):
                     stage_ms[s] += ev[s].elapsed_time(ev[s + 1])
         launches = args.steps * ITERS
         stage_avg = {name: stage_ms[i] / launches for i, name in enumerate(STAGE_NAMES)}
-        res_ms = sum(stage_avg["res%d" % i] for i in range(7)) / 7.0       # one residual-block launch
+        # from the timed steps: head kernel and the 7 residual blocks
+        head_ms = sum(events[k][it][0].elapsed_time(events[k][it][1])
+                      for k in range(args.steps) for it in range(ITERS)) / launches
+        res7_ms = sum(events[k][it][1].elapsed_time(events[k][it][8])
+                      for k in range(args.steps) for it in range(ITERS)) / launches
+        stacked = args.precision != "fp32" and v <= 128 and os.environ.get("DANCE_RES_STACK", "1") != "0"
+        res_ms = res7_ms / 7.0                                  # per residual block
         res_tflops = 2.0 * MACS_RES_BLOCK * v * n / (res_ms * 1e-3) / 1e12  # algorithmic
-        head_ms = stage_avg["head"]
         gather_gbps = GATHER_BYTES_PER_VERTEX * v * n / (head_ms * 1e-3) / 1e9
         layout_ms = (sum(a.elapsed_time(b_) for a, b_ in layout_ev) / args.steps) if pre is None else 0.0
         ms_per_step = elapsed / args.steps * 1e3
@@ -269,11 +284,18 @@ def main():
             terms = 3 if args.precision == "fp16x3" else 1
             # every algorithmic product is three f16 MFMA products (A_lo*B_hi + A_hi*B_lo +
             # A_hi*B_hi); the roofline prices the EXECUTED f16 MFMA flops against the f16 peak
-            roof = {"kernel": "k_conv16s<%d> (residual SnakeBlock 128->128, k=9, %s f16 MFMA 16x16x32)"
-                              % (rt, "split-half" if terms == 3 else "single-term"),
+            kname = ("k_res_stack16s<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
+                     "%s f16 MFMA 16x16x32)" if stacked else
+                     "k_conv16%s<%d,%d> (residual SnakeBlock 128->128, k=9, %s f16 MFMA; 7 launches "
+                     "between the two events, figures per launch)")
+            kname = kname % ((rt, terms, "split-half" if terms == 3 else "single-term") if stacked else
+                             ("s" if rt <= 4 else "", rt, terms, "split-half" if terms == 3 else "single-term"))
+            roof = {"kernel": kname,
                     "bound": "mfma", "achieved": terms * res_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": terms * res_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                    "avg_launch_ms": res_ms, "algorithmic_TFLOPs": res_tflops, "mfma_per_product": terms,
+                    "avg_launch_ms": res7_ms if stacked else res_ms,
+                    "algorithmic_GFLOP_per_launch": 2.0 * MACS_RES_BLOCK * v * n * (7 if stacked else 1) / 1e9,
+                    "algorithmic_TFLOPs": res_tflops, "mfma_per_product": terms,
                     "note": "achieved = executed f16 MFMA flops (%d x algorithmic) / spacing of the HIP events "
                             "around the launch in the timed steps (includes the ~12 us inter-kernel gap; "
                             "rocprofv3 kernel durations in profiles/ are that much shorter)" % terms}
@@ -315,7 +337,8 @@ def main():
                        "standalone_frac_of_hbm_peak": GATHER_BYTES_PER_VERTEX * v * n / (gather_alone_ms * 1e-3) / 1e9
                                                       / PEAK_HBM_GBPS},
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
-            "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms),
+            "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms,
+                             note="instrumented pass after the timed region (14 events per iteration)"),
             "streams": args.streams,
             "feat_prep": feat_prep,
             "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,

@@ -607,6 +607,114 @@ __global__ __launch_bounds__(256, 2) void k_conv16s(Conv16Args a, int n)
     }
 }
 
+// All residual SnakeBlocks of one _SnakeNet in ONE launch (V <= 128): a workgroup takes a
+// contour through the 7 blocks with the activations resident in LDS.  Block l reads the image,
+// every wave finishes its MFMAs (barrier), then the epilogue adds the residual from the image,
+// writes block l's output to its state slot in HBM (fusion / prediction read it later) AND
+// back into the same LDS words as block l + 1's input (barrier).  Against 7 launches of
+// k_conv16s: one launch gap and one kernel tail instead of 7, no activation re-read, no chunk
+// staging inside the MFMA loops.
+struct Stack16Args {
+    _Float16 *state;                // (n, 1 + nlayers slots) P16: slot l = input of block l
+    long long stride, slot;         // halfs per contour / per slot
+    const h8 *w[7];
+    const float *bias_s[7], *scale[7], *shift[7];
+    float winv[7];
+    int dilation[7];
+    int v, nlayers;
+};
+
+template <int RT, int TERMS>
+__global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
+{
+    static_assert(RT <= 4, "rings of at most 128 vertices");
+    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NW = 4, NB = 4, CT = 2 * RT;
+    using G = Geo<RT, CBC>;
+    using S = StageGeo<RT, CBC, NW>;
+    extern __shared__ __attribute__((aligned(16))) char xs[];   // chunk images 0 | 1 = 128 channels
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int o0 = wave * 32;
+    const int v = a.v;
+    const long long wbs_b = 128 * 16, wts_b = 16 * wbs_b, wps_b = 9 * wts_b;
+    const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
+    auto nohook = [](int) __attribute__((always_inline)) {};
+
+    for (long long nn = blockIdx.x; nn < n; nn += gridDim.x) {
+        _Float16 *sn = a.state + nn * a.stride;
+        {
+            u32x4 sreg[S::N];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                stage_load<RT, CBC, NW>(sreg, 0, S::N, reinterpret_cast<const char *>(sn) + (long long)c * CBC * v * 16,
+                                        v, wave, lane);
+                stage_commit<RT, CBC, NW>(sreg, xs, c * G::BYTES, v, wave, lane);
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < a.nlayers; ++l) {
+            f32x4 acc[2][CT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s[l] + o0 + 16 * i + 4 * q4);
+                const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < CT; ++j)
+                    acc[i][j] = bv;
+            }
+            const char *wl = reinterpret_cast<const char *>(a.w[l]) + (long long)o0 * 16;
+            const int dil = a.dilation[l];
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c)
+                mfma16_core_s<RT, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b, wlane,
+                                                      wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, nohook);
+            __syncthreads();                    // every wave has read the whole image
+            // epilogue: lane = vertex 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3; indices
+            // made opaque so the compiler does not hoist the address math over the MFMAs
+            int ce = c16, qe = q4;
+            asm volatile("" : "+v"(ce), "+v"(qe));
+            _Float16 *yslot = sn + (l + 1) * a.slot;
+            const float winv = a.winv[l];
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int ob = o0 + 16 * i2 + 4 * qe;
+                const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale[l] + ob);
+                const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift[l] + ob);
+                const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+                const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
+                const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const int vv = j * 16 + ce;
+                    if (vv >= v)
+                        continue;
+                    char *q = xs + xchunk * G::BYTES + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
+                    const h4 rh = *reinterpret_cast<const h4 *>(q);
+                    const h4 rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
+                    h4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float x = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
+                        x += (float)rh[i] + (float)rl[i];
+                        _Float16 xh, xl;
+                        dance::split_half(x, xh, xl);
+                        hi[i] = xh;
+                        lo[i] = xl;
+                    }
+                    // next block's input, in place (this lane owns these two half-words)
+                    *reinterpret_cast<h4 *>(q) = hi;
+                    *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
+                    _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
+                    *reinterpret_cast<h4 *>(d) = hi;
+                    *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
+                }
+            }
+            __syncthreads();                    // image = block l + 1's input
+        }
+    }
+}
+
 // fusion (1024 -> 256, max over the ring) + row constant + prediction[0] (1280 -> 256, ReLU)
 // in one pass over the 1024-channel state: 8 waves, two 32-channel tiles each; waves 0-3 own
 // the fusion outputs, waves 4-7 the prediction outputs (weights packed as one 512-output GEMM).
@@ -984,6 +1092,28 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
         return launch_check(__func__);
     }
     LAUNCH_RT(k_conv16, rt, mfma_terms, grid, dim3(256), lds, (hipStream_t)stream, "dance_conv16", a, n);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int64_t stride, int64_t slot,
+                                 int n, int v, int mfma_terms, void *stream)
+{
+    DANCE_REQUIRE(net != nullptr && n >= 0 && v >= 16 && v <= 128);
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(state != nullptr);
+    Stack16Args a;
+    a.state = (_Float16 *)state; a.stride = stride; a.slot = slot; a.v = v; a.nlayers = 7;
+    for (int i = 0; i < 7; ++i) {
+        DANCE_REQUIRE(net->res_w[i] && net->res_bs[i] && net->res_scale[i] && net->res_shift[i]);
+        DANCE_REQUIRE(net->dilation[i] >= 1 && net->dilation[i] * 4 <= 16);
+        a.w[i] = (const h8 *)net->res_w[i]; a.bias_s[i] = net->res_bs[i]; a.scale[i] = net->res_scale[i];
+        a.shift[i] = net->res_shift[i]; a.winv[i] = net->res_winv[i]; a.dilation[i] = net->dilation[i];
+    }
+    const int rt = pick_rt16(v);
+    const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // the whole 128-channel image
+    LAUNCH_RT24(k_res_stack16s, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
     return launch_check(__func__);
 }
 

@@ -205,7 +205,8 @@ class ContourDeformer:
     def evolve(self, it, feat, att, locations, image_idx, whs, *, use_att, clip_first, clip_max,
                x_in=None, out=None, stage_events=None):
         """One iteration with deformer `it` (RefineNet.evolve, snake_head.py:1624-1713).
-        stage_events: optional list of EVOLVE_EVENTS recorded torch.cuda.Event(enable_timing)
+        stage_events: optional list of EVOLVE_EVENTS recorded torch.cuda.Event(enable_timing),
+        entries may be None (boundary not timed)
         (single-chunk calls only) -- bench instrumentation."""
         net = self.nets[it]
         n, v, _ = locations.shape
@@ -228,7 +229,7 @@ class ContourDeformer:
         if stage_events is not None:
             if n > chunk or len(stage_events) != EVOLVE_EVENTS:
                 raise RuntimeError("stage events need a single-chunk call and %d events" % EVOLVE_EVENTS)
-            ev = (ctypes.c_void_p * EVOLVE_EVENTS)(*[e.cuda_event for e in stage_events])
+            ev = (ctypes.c_void_p * EVOLVE_EVENTS)(*[None if e is None else e.cuda_event for e in stage_events])
         with torch.cuda.device(dev):
             stream = current_stream()
             for n0 in range(0, n, chunk):

@@ -211,7 +211,10 @@ int64_t dance_snake_workspace_bytes(int n, int v);
  *   replaces the gather (Dsnake init path), else NULL;
  *   stage_events_host: NULL, or DANCE_EVOLVE_EVENTS hipEvent_t handles recorded on `stream`
  *   before the first kernel and after each stage (head | res0..6 | fusion | row constant |
- *   prediction[0] | prediction[2] | offset update) -- timing instrumentation for bench.py. */
+ *   prediction[0] | prediction[2] | offset update) -- timing instrumentation for bench.py;
+ *   individual entries may be NULL (that boundary is then not recorded: an event record
+ *   costs ~4 us of stream time).  When the residual blocks run as one launch
+ *   (dance_res_stack16) the events after res0..res5 follow it immediately. */
 #define DANCE_EVOLVE_EVENTS 14
 int dance_snake_evolve(const dance_snake_net *net_host, const float *feat, const float *att,
                        const float *loc, const int32_t *image_idx, const float *whs,
@@ -279,6 +282,13 @@ typedef struct dance_snake_net16 {
     int dilation[7];
     int feat_channels;
 } dance_snake_net16;
+
+/* The 7 residual SnakeBlocks (res_* fields of the net) in one launch, v <= 128: state is the
+ * (n, 8 slots) P16 block, slot 0 = head output (input), slots 1..7 receive the block outputs;
+ * same results as 7 dance_conv16 calls (bit-identical), one kernel tail and launch gap
+ * instead of 7.  reference: _SnakeNet.forward snake_head.py:262-268. */
+int dance_res_stack16(const dance_snake_net16 *net_host, void *state, int64_t stride, int64_t slot,
+                      int n, int v, int mfma_terms, void *stream);
 
 /* dance_snake_evolve in the fast precision mode (same workspace size, same stage events;
  * the fusion / row-constant / prediction[0] stages are one kernel).  net32 is only needed

@@ -3,7 +3,8 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from dance_amd import config, modules, ops, snake, synthetic
 dev = torch.device('cuda')
-b, per, v, CH, HF, WF = 16, 100, 128, 256, 200, 304
+import os
+b, per, v, CH, HF, WF = int(os.environ.get("GB", "16")), 100, 128, 256, 200, 304
 n = b * per
 cfg = config.dance_r50(num_sampling=v, num_convs=0)
 sd = {k: t.clone() for k, t in modules.RefineNet(cfg).state_dict().items()}
