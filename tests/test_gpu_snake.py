@@ -269,3 +269,30 @@ def test_deterministic_and_chunked(device):
     want = snake_ref.dance_deform(sd, feats.cpu(), loc.cpu(), idx.cpu(), [(200, 304)] * 3, whs.cpu())
     for i in range(3):
         assert coord_rel_err(a[i], want[i]) < REL_TOL
+
+
+@pytest.mark.parametrize("v", [16, 40, 64, 100, 128])
+def test_res_stack_equals_seven_launches(device, v):
+    """dance_res_stack16 (7 residual blocks, activations resident in LDS) is bit-identical to
+    7 dance_conv16 launches through HBM, for both MFMA term counts."""
+    import ctypes
+    from dance_amd._lib import check, current_stream, lib, ptr
+    cfg, sd, _ = dance_state_dict(99, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
+    s16 = net.struct16
+    n, slot = 37, 256 * v
+    x = torch.randn((n, 128, v), generator=torch.Generator().manual_seed(v)) * 2
+    for terms in (3, 1):
+        a = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
+        a[:, 0] = ops.to_p16(x.to(device))[:, 0]
+        b = a.clone()
+        with torch.cuda.device(device):
+            st = current_stream()
+            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(a), a.stride(0), slot, n, v, terms, st), "stack")
+            for i in range(7):
+                check(lib().dance_conv16(ptr(b[:, i]), b.stride(0), slot, s16.res_w[i], s16.res_bs[i],
+                                         s16.res_winv[i], s16.res_scale[i], s16.res_shift[i], None, 1, 1, 0,
+                                         ptr(b[:, i + 1]), b.stride(0), slot, None, 0, n, v, 128, 128, 9,
+                                         s16.dilation[i], terms, st), "conv16")
+        assert torch.equal(a, b), (v, terms)
+        assert bool(torch.isfinite(a.float()).all()) and float(a[:, 7].float().abs().max()) > 0
