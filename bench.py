@@ -296,9 +296,9 @@ def main():
                     "avg_launch_ms": res7_ms if stacked else res_ms,
                     "algorithmic_GFLOP_per_launch": 2.0 * MACS_RES_BLOCK * v * n * (7 if stacked else 1) / 1e9,
                     "algorithmic_TFLOPs": res_tflops, "mfma_per_product": terms,
-                    "note": "achieved = executed f16 MFMA flops (%d x algorithmic) / spacing of the HIP events "
-                            "around the launch in the timed steps (includes the ~12 us inter-kernel gap; "
-                            "rocprofv3 kernel durations in profiles/ are that much shorter)" % terms}
+                    "note": "achieved = executed f16 MFMA flops (%d x algorithmic) / spacing of the two HIP events "
+                            "around the residual blocks in the timed steps (event spacing includes the "
+                            "inter-kernel gap, ~10 us per launch)" % terms}
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"
             gkernel = "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt
         else:
