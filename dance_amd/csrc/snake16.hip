@@ -735,25 +735,29 @@ struct Fuse16Args {
 template <int RT, int TERMS>
 __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
 {
-    constexpr int CBC = 8, NST = 4, AD = 2, NW = 8, NCH = 1024 / (CBC * 8);
+    // K = 1024 as one flat sequence of 64 steps of 16 channels: weights rotate through two
+    // buffers over the whole sequence (no refill bubble at chunk boundaries), activations come
+    // from 128-channel chunk images double-buffered in LDS, one staged load per step, ONE
+    // barrier per chunk (the other image was last read two chunks ago).
+    constexpr int CBC = 16, NST = 8, NW = 8, NCH = 1024 / (CBC * 8), NT = NST * RT;
     using G = Geo<RT, CBC>;
     using S = StageGeo<RT, CBC, NW>;
+    constexpr int SSTEP = 2 * G::VP * 16;
     extern __shared__ __attribute__((aligned(16))) char xs[];
     __shared__ float gs[256];
-    __shared__ float hp[512];
+    __shared__ float hp[8 * 256];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int o0 = wave * 64;
     const int v = a.v;
-    const long long wbs_b = 512 * 16, wts_b = 128 * wbs_b;
+    const long long wbs_b = 512 * 16, wps_b = 128 * wbs_b, wstep_b = 2 * wbs_b;
     const unsigned wlane = (unsigned)(h * 512 + r) * 16u;
     const int ostep = gridDim.x;
+    const char *wbase = reinterpret_cast<const char *>(a.w) + (long long)o0 * 16;
 
     auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
-        const int c0 = c * CBC * 8;
-        return reinterpret_cast<const char *>(a.x + m * a.x_stride + (c0 >> 7) * a.x_slot_stride) +
-               (long long)((c0 & 127) >> 3) * v * 16;
+        return reinterpret_cast<const char *>(a.x + m * a.x_stride + c * a.x_slot_stride);
     };
 
     u32x4 sreg[S::N];
@@ -762,55 +766,123 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
     stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
     __syncthreads();
 
+    unsigned pl[RT];                            // this lane's word in each vertex tile (no ring shift: k = 1)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        pl[rt] = (unsigned)(h * G::VP + min(rt * 32 + r, v - 1)) * 16u;
+
     int k = 0;
     for (; nn < n; nn += ostep) {
         f32x16 acc[2][RT];
         init_acc16<RT, 2>(acc, a.bias_s, o0, h, 1.0f);
+        h8 ah[2][2], al[2][2];
+#define F_LOAD_A(SLOT, PTR)                                                                       \
+    do {                                                                                          \
+        const char *pa_ = (PTR);                                                                  \
+        _Pragma("unroll") for (int ot_ = 0; ot_ < 2; ++ot_) {                                     \
+            ah[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wlane + ot_ * 512);               \
+            if constexpr (TERMS == 3)                                                             \
+                al[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + ot_ * 512);   \
+        }                                                                                         \
+    } while (0)
+        F_LOAD_A(0, wbase);
         for (int c = 0; c < NCH; ++c, ++k) {
             const unsigned cur = (k & 1) * G::BYTES, nxt = ((k + 1) & 1) * G::BYTES;
             const bool last = c + 1 == NCH;
             const bool has_next = !last || nn + ostep < n;
             const char *ssrc = has_next ? chunk_src(last ? nn + ostep : nn, last ? 0 : c + 1) : chunk_src(nn, c);
-            auto hook = [&](int s) __attribute__((always_inline)) {
-                stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
-            };
-            mfma16_core<RT, 2, NST, AD, 2, TERMS>(acc, xs, cur, v,
-                                        reinterpret_cast<const char *>(a.w) + ((long long)(c * CBC) * 512 + o0) * 16,
-                                        wlane, wts_b, wts_b, 2 * wbs_b, 1, 1, r, h, hook);
-            __syncthreads();
+            const char *wchunk = wbase + (long long)c * NST * wstep_b;
+            h8 bh[2], bl[2];
+#define F_LOAD_B(Q)                                                                               \
+    do {                                                                                          \
+        constexpr int s_ = (Q) / RT, rt_ = (Q) % RT;                                              \
+        bh[(Q) % 2] = *reinterpret_cast<const h8 *>(xs + cur + pl[rt_] + s_ * SSTEP);             \
+        if constexpr (TERMS == 3)                                                                 \
+            bl[(Q) % 2] = *reinterpret_cast<const h8 *>(xs + cur + pl[rt_] + s_ * SSTEP + G::PLANE); \
+    } while (0)
+            F_LOAD_B(0);
+            dance::static_for<0, NT>([&](auto qq) __attribute__((always_inline)) {
+                constexpr int q = decltype(qq)::value, s = q / RT, rt = q % RT;
+                if constexpr (rt == 0) {
+                    // next step's weights: the sequence runs on linearly into the next chunk
+                    if (s + 1 < NST || !last)
+                        F_LOAD_A((s + 1) % 2, wchunk + (s + 1) * wstep_b);
+                    stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
+                }
+                if constexpr (q + 1 < NT)
+                    F_LOAD_B(q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (TERMS == 3) {
+                    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % 2][0], bh[q % 2], acc[0][rt], 0, 0, 0);
+                    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % 2][1], bh[q % 2], acc[1][rt], 0, 0, 0);
+                    acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2][0], bl[q % 2], acc[0][rt], 0, 0, 0);
+                    acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2][1], bl[q % 2], acc[1][rt], 0, 0, 0);
+                }
+                acc[0][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2][0], bh[q % 2], acc[0][rt], 0, 0, 0);
+                acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2][1], bh[q % 2], acc[1][rt], 0, 0, 0);
+            });
+#undef F_LOAD_B
             if (has_next)
                 stage_commit<RT, CBC, NW>(sreg, xs, nxt, v, wave, lane);
             __syncthreads();
         }
+#undef F_LOAD_A
         int re = r, he = h;
         asm volatile("" : "+v"(re), "+v"(he));
         if (wave < 4) {
-            // global state = max over the ring of the fusion output (snake_head.py:271-272)
+            // global state = max over the ring of the fusion output (snake_head.py:271-272).
+            // The 32 cross-lane reductions run side by side, one butterfly round at a time
+            // (32 independent shuffles per round instead of 32 serial five-round chains).
+            float m[2][16];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    float m = -INFINITY;
+                    float mm = -INFINITY;
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
                         if (rt * 32 + re < v)
-                            m = dance::nan_max(acc[ot][rt][q] * a.winv, m);
-#pragma unroll
-                    for (int s = 16; s >= 1; s >>= 1)
-                        m = dance::nan_max(__shfl_xor(m, s, 64), m);
-                    if (re == 0)
-                        gs[o0 + ot * 32 + (q & 3) + 8 * (q >> 2) + 4 * he] = m;
+                            mm = dance::nan_max(acc[ot][rt][q] * a.winv, mm);
+                    m[ot][q] = mm;
                 }
+#pragma unroll
+            for (int s = 16; s >= 1; s >>= 1)
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        m[ot][q] = dance::nan_max(__shfl_xor(m[ot][q], s, 64), m[ot][q]);
+            if (re == 0) {
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        gs[o0 + ot * 32 + (q & 3) + 8 * (q >> 2) + 4 * he] = m[ot][q];
+            }
         }
         __syncthreads();
-        {   // row constant h[o] = pb[o] + sum_g wg[g][o] * G[g], two half sums per output
-            const int o = t & 255, half = t >> 8;
-            float s = 0.0f;
-            const float *wgp = a.wg + (long long)half * 128 * 256 + o;
-#pragma unroll 8
-            for (int kk = 0; kk < 128; ++kk)
-                s = fmaf(wgp[(long long)kk * 256], gs[half * 128 + kk], s);
-            hp[t] = s;
+        {   // row constant h[o] = pb[o] + sum_g wg[g][o] * G[g]: 8 partial sums per output, each
+            // thread 4 consecutive outputs x 32 values of g, 8 16-byte loads in flight per round
+            // (a 128-step dependent loop per thread was latency-bound: ~25 us per contour)
+            const int o4 = (t & 63) * 4, part = t >> 6;
+            const float *wgp = a.wg + (long long)part * 32 * 256 + o4;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 1
+            for (int k0 = 0; k0 < 32; k0 += 8) {            // 8 loads in flight per round
+                float4 w4[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+                    w4[kk] = *reinterpret_cast<const float4 *>(wgp + (k0 + kk) * 256);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float gk = gs[part * 32 + k0 + kk];
+                    s0 = fmaf(w4[kk].x, gk, s0);
+                    s1 = fmaf(w4[kk].y, gk, s1);
+                    s2 = fmaf(w4[kk].z, gk, s2);
+                    s3 = fmaf(w4[kk].w, gk, s3);
+                }
+            }
+            *reinterpret_cast<float4 *>(hp + part * 256 + o4) = float4{s0, s1, s2, s3};
         }
         __syncthreads();
         if (wave >= 4) {
@@ -824,7 +896,11 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int o = p0 + ot * 32 + 8 * g + 4 * he + i;
-                        hc[i] = a.pb[o] + hp[o] + hp[256 + o];
+                        float hs = a.pb[o];
+#pragma unroll
+                        for (int pp = 0; pp < 8; ++pp)
+                            hs += hp[pp * 256 + o];
+                        hc[i] = hs;
                     }
                     const int ob = p0 + ot * 32 + 8 * g;
 #pragma unroll
@@ -1133,7 +1209,7 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
     DANCE_REQUIRE(v <= 128);        // larger rings: unfused dance_conv16 sequence (accumulators)
     const int rt = v <= 64 ? 2 : 4;
-    const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // two 64-channel chunk images
+    const size_t lds = (size_t)2 * 2 * 16 * (rt * 32 + 1) * 16;    // two 128-channel chunk images
     static const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
     dim3 grid(slots > 0 && slots < n ? slots : n);
     LAUNCH_RT24(k_fuse16, rt, mfma_terms, grid, dim3(512), lds, (hipStream_t)stream, "dance_fuse16", a, n);
