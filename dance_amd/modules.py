@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import ops, timer
 from .config import SnakeHeadConfig
 from .snake import ContourDeformer, SnakeNetWeights, sub_state_dict
 from .structures import ExtremePoints, PolygonPoints
@@ -247,20 +247,23 @@ class RefineNet(_SnakeHeadBase):
 
     def deform(self, features, locations, image_idx, image_sizes, whs):
         """The `snake_deformation` scope (snake_head.py:1822-1862): per-iteration contours."""
-        d, nhwc, att = self._features(features)
+        with timer.env("snake_feat_prep"):
+            d, nhwc, att = self._features(features)
         # DANCE_STREAMS=2: halves of the contours on two HIP streams (bit-identical, ~8 % faster
         # on large batches; ContourDeformer.deform)
-        return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc",
-                        streams=int(os.environ.get("DANCE_STREAMS", "1")))
+        with timer.env("snake_deformation"):
+            return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc",
+                            streams=int(os.environ.get("DANCE_STREAMS", "1")))
 
     def single_test(self, features, pred_instances):
         """snake_head.py:1763-1869 (one image)."""
-        if self.initial == "octagon":
-            locations, _ = self._sample_octagons(pred_instances)
-        elif self.initial == "box":
-            locations, _ = self._sample_boxes(pred_instances[:1])
-        else:
-            raise ValueError("Invalid initial!")
+        with timer.env("contour_sampling"):                    # snake_head.py:1786
+            if self.initial == "octagon":
+                locations, _ = self._sample_octagons(pred_instances)
+            elif self.initial == "box":
+                locations, _ = self._sample_boxes(pred_instances[:1])
+            else:
+                raise ValueError("Invalid initial!")
         if len(locations) == 0:
             return pred_instances, {}
         image_sizes = pred_instances[0].image_size
@@ -268,8 +271,9 @@ class RefineNet(_SnakeHeadBase):
         bboxes = pred_instances[0].pred_boxes.tensor
         whs = torch.stack([bboxes[:, 2] - bboxes[:, 0], bboxes[:, 3] - bboxes[:, 1]], dim=1)
         preds = self.deform(features, locations, None, image_sizes, whs)
-        inst = pred_instances[0]
-        inst.pred_polys = self.polygon_cls(preds[-1])
+        with timer.env("snake_postprocess"):                   # snake_head.py:1864
+            inst = pred_instances[0]
+            inst.pred_polys = self.polygon_cls(preds[-1])
         return [inst], {}
 
     def forward(self, features, pred_instances=None, targets=None):

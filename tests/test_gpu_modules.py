@@ -84,3 +84,27 @@ def test_bottom_out_channels_last_feeds_the_gather(device):
     whs = torch.stack([b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], 1)
     want = snake_ref.dance_deform(sd, full, init, None, (96, 128), whs)
     assert coord_rel_err(res[0].pred_polys.tensor, want[-1]) < REL_TOL
+
+
+def test_timer_scopes_match_the_reference_names(device):
+    """dance_amd.timer records device time under the reference's scope names (timer.py,
+    snake_head.py:1786-1864) when enabled, and nothing when disabled."""
+    from dance_amd import timer
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("smooth_single_box_v128")
+    net = _module(cfg, sd, device)
+    inst = FakeInstances(sizes, pred_boxes=FakeBoxes(g["boxes"][0].to(device)))
+    timer.reset()
+    with torch.no_grad():
+        net(feats.to(device), [inst], None)
+    assert timer.total_times() == {}
+    timer.enable_all()
+    try:
+        with torch.no_grad():
+            net(feats.to(device), [inst], None)
+        stats = timer.total_times()
+    finally:
+        timer.disable_all()
+        timer.reset()
+    assert set(stats) == {"contour_sampling", "snake_feat_prep", "snake_deformation", "snake_postprocess"}
+    assert all(ms >= 0.0 and n == 1 for ms, n in stats.values())
+    assert stats["snake_deformation"][0] > stats["contour_sampling"][0]
