@@ -2,7 +2,7 @@
 oracle/gen_golden.py produced with the reference's own code."""
 import torch
 
-from _util import dance_state_dict, dsnake_state_dict, golden, rel_err
+from _util import CHAIN_TOL_WHITE, dance_state_dict, dsnake_state_dict, golden, rel_err
 from dance_amd import synthetic
 from oracle import extreme_utils_ref as cref
 from oracle import snake_ref
@@ -94,11 +94,21 @@ def dance_case_inputs(tag):
 def test_dance_chain_restatement():
     for tag in DANCE_CASES:
         g, cfg, sd, feats, image_idx, sizes = dance_case_inputs(tag)
-        preds = snake_ref.dance_deform(sd, feats, g["init"], image_idx, sizes, g["whs"],
-                                       attention=cfg.attention, individual_scale=cfg.individual_scale,
-                                       de_loc_type=cfg.de_loc_type)
+        kw = dict(attention=cfg.attention, individual_scale=cfg.individual_scale,
+                  de_loc_type=cfg.de_loc_type)
+        # every iteration on IDENTICAL inputs (the fixture's previous contours): 1e-5
         for i in range(3):
-            assert rel_err(preds[i], g["pred%d" % i]) < 1e-5, (tag, i)
+            prev = g["init"] if i == 0 else g["pred%d" % (i - 1)]
+            one = snake_ref.dance_evolve(snake_ref.sub_state_dict(sd, "deformer%d." % i), feats,
+                                         prev.clone(), image_idx, sizes, g["whs"],
+                                         att=(cfg.attention and i > 0), **kw)
+            assert rel_err(one, g["pred%d" % i]) < 1e-5, (tag, i)
+        # the whole chain: white-noise fixtures are chaotic (the host CPU's own summation
+        # order moves iteration 2 by ~1e-4, _util.CHAIN_TOL_WHITE), band-limited ones are not
+        preds = snake_ref.dance_deform(sd, feats, g["init"], image_idx, sizes, g["whs"], **kw)
+        tol = (1e-5, 1e-5, 1e-5) if int(g["smooth"]) else CHAIN_TOL_WHITE
+        for i in range(3):
+            assert rel_err(preds[i], g["pred%d" % i]) < tol[i], (tag, i)
 
 
 def test_dsnake_restatement():
