@@ -26,6 +26,7 @@ SOURCES = [
     ("snake_mfma.hip", []),
     ("snake16.hip", []),
     ("featprep16.hip", []),
+    ("raster.hip", ["-ffp-contract=off"]),
 ]
 HEADERS = ["common.h", "sampling.h", "p16.h", os.path.join("..", "..", "include", "dance_hip.h")]
 

@@ -95,6 +95,35 @@ int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamm
                   const float *beta, float eps, int groups, void *out16, float *out_nhwc,
                   int b, int c, int h, int w, void *stream);
 
+/* --------------------------------------- polygon -> RLE mask ------ */
+/* reference call sites: get_polygon_rles = mask_util.merge(mask_util.frPyObjects([p.tolist()],
+ * h, w)) per instance, on the CPU after a device -> host copy (core/evaluation/
+ * coco_evaluation.py:311-318,352-357; core/modeling/postprocessing.py:266-274;
+ * core/modeling/dsnake_baseline/postprocessing.py:13-21,71).  The arithmetic is pycocotools'
+ * (cocoapi common/maskApi.c rleFrPoly; not part of the reference tree, unpinned there:
+ * README.md:27); results are bit-identical to oracle/rle_ref.c, the restatement of that
+ * published algorithm.
+ *   polys (n,v,2) f32 x,y in pixels of the (h,w) image, v <= 512; sizes (n,2) i32 (h,w) per
+ *   polygon, or NULL = the scalars h, w for all (h <= 327680, h*w < 2^31);
+ *   counts (n,cap) u32: run lengths in column-major order, first run = zeros; m (n) i32 = number
+ *   of runs (rows with m > cap hold the first cap runs); area (n) u32 = sum of the runs of ones
+ *   (rleArea), may be NULL; status (n) i32, may be NULL: 0 ok, 1 = m > cap, 2 = size not
+ *   supported.  Non-finite coordinates convert to 0 (the library's conversion is undefined). */
+int dance_polygon_rle(const float *polys, const int32_t *sizes, int n, int v, int h, int w,
+                      uint32_t *counts, int cap, int32_t *m, uint32_t *area, int32_t *status,
+                      void *stream);
+/* rleToString of the same library (the "counts" bytes the reference's evaluator stores,
+ * coco_evaluation.py:369-374).  len (n) i32 = bytes each row needs.  str NULL: lengths only.
+ * offsets NULL: row i is written at str + i * str_cap; else at str + offsets[i], offsets being
+ * (n+1) i64 (exclusive prefix sum of the lengths): one packed buffer, one device -> host copy.
+ * A row that does not fit its room is left incomplete (its len says so). */
+int dance_rle_to_string(const uint32_t *counts, const int32_t *m, int n, int cap, uint8_t *str,
+                        const int64_t *offsets, int64_t str_cap, int32_t *len, void *stream);
+/* rleDecode: mask (n, w, h) u8 -- the library's column-major memory order, mask[i][x][y] --
+ * zero-filled on the stream, then the runs of ones are written. */
+int dance_rle_decode(const uint32_t *counts, const int32_t *m, int n, int cap, uint8_t *mask,
+                     int h, int w, void *stream);
+
 /* ------------------------------------------------- contour initialisation (a11-a15) - */
 enum {
     DANCE_POLY_RAW = 0,      /* src = polygons (n,e,2)                                  */
