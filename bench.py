@@ -37,6 +37,22 @@ PEAK_F16_MFMA_TFLOPS = 2500.0                         # MI355X_MICROARCH.md, BF1
 PEAK_HBM_GBPS = 8000.0
 
 
+def measured_traffic(kernel, workgroups):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/hbm_traffic.json,
+    written by tools/traffic_json.py from separate rocprofv3 --pmc runs of this same command:
+    counters cannot be read inside the timed run).  None when no pass covers this launch shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None, None
+    for key, val in t["kernels"].items():
+        name, wg = key.split("|")
+        if name.startswith(kernel) and int(wg) == workgroups:
+            return val["bytes"], t["source"]
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +272,48 @@ def main():
                          "frac_of_f16_peak": 3 * fp_flops / hip_ms / 1e9 / PEAK_F16_MFMA_TFLOPS,
                          "stock_torch_ms": stock_ms, "speedup_vs_stock": stock_ms / hip_ms}
             del net2, layers
+        # the step after the path: deformed contours -> RLE masks, the
+        # reference's get_polygon_rles (coco_evaluation.py:311-318; one pycocotools call per
+        # instance on the host there).  Contours clipped to the image as postprocessing does.
+        from dance_amd import rle
+
+        def time_rle(polys):
+            for _ in range(2):
+                r = rle.polygon_rle(polys, (h, w))
+            cap = r.counts.size(1)                            # settled capacity: one launch per call
+            g0.record()
+            for _ in range(10):
+                r = rle.polygon_rle(polys, (h, w), cap=cap)
+            g1.record()
+            torch.cuda.synchronize()
+            ms = g0.elapsed_time(g1) / 10
+            t0 = time.perf_counter()
+            strings = r.strings()
+            return r, strings, {"ms": ms, "polygons_per_s": n / (ms * 1e-3), "mean_runs": float(r.m.float().mean()),
+                                "strings_ms_incl_d2h": (time.perf_counter() - t0) * 1e3}
+
+        ellipses = synthetic.make_circle_contours(boxes, v).to(dev)
+        polys = out[:n].clone()
+        polys[..., 0].clamp_(0, w)
+        polys[..., 1].clamp_(0, h)
+        r, strings, fig = time_rle(ellipses)
+        _, _, fig_jagged = time_rle(polys)
+        mask_rle = dict({"stage": "polygon -> RLE of %d %d-vertex contours at %dx%d (k_polygon_rle, one workgroup per "
+                                  "polygon, parity bitmap in LDS); outside the timed step" % (n, v, h, w),
+                         "contours": "ellipses inscribed in the synthetic boxes (radius 20-100 px)"}, **fig)
+        mask_rle["deformed_contours"] = dict(fig_jagged, note="the bench's own output: white-noise features make "
+                                             "these contours jagged (perimeters of ~10^4 px), a stress case")
+        mask_rle["note"] = "includes the wrapper's capacity check (one device sync per call)"
+        polys = ellipses
+        if not args.no_cpu_baseline:
+            from oracle import rle_ref
+            sample = polys[:200].cpu().numpy()
+            t0 = time.perf_counter()
+            ref_strings = [rle_ref.to_string(rle_ref.fr_poly(p_, h, w)) for p_ in sample]
+            dt = time.perf_counter() - t0
+            assert ref_strings == strings[:200], "bench: RLE strings differ from the oracle"
+            mask_rle["cpu_oracle"] = {"polygons_per_s": 200 / dt, "cores": 1, "kind": "port",
+                                      "sample": "first 200 of the same contours, oracle/rle_ref.c through ctypes"}
 
     if rank == 0:
         # per-stage device time from the HIP events recorded inside the timed steps
@@ -299,6 +357,9 @@ def main():
                     "note": "achieved = executed f16 MFMA flops (%d x algorithmic) / spacing of the two HIP events "
                             "around the residual blocks in the timed steps (event spacing includes the "
                             "inter-kernel gap, ~10 us per launch)" % terms}
+            if terms == 3:
+                roof["traffic"], roof["traffic_source"] = measured_traffic(
+                    "k_res_stack16s" if stacked else "k_conv16s" if rt <= 4 else "k_conv16<", n)
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"
             gkernel = "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt
         else:
@@ -341,6 +402,7 @@ def main():
                              note="instrumented pass after the timed region (14 events per iteration)"),
             "streams": args.streams,
             "feat_prep": feat_prep,
+            "mask_rle": mask_rle,
             "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,
                                  "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),
                                  "note": "reference scope `contour_sampling`, outside the timed step"},

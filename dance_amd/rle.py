@@ -24,7 +24,7 @@ def _as_polys(polygons):
     if polygons.dim() == 2:                      # the reference's flattened (N, 2V)
         if polygons.size(1) % 2:
             raise RuntimeError("flattened polygons must have an even number of columns")
-        polygons = polygons.view(polygons.size(0), -1, 2)
+        polygons = polygons.reshape(polygons.size(0), polygons.size(1) // 2, 2)
     if polygons.dim() != 3 or polygons.size(2) != 2:
         raise RuntimeError("polygons must be (N,V,2) or (N,2V)")
     if not 1 <= polygons.size(1) <= MAX_VERTICES:

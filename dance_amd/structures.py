@@ -50,6 +50,16 @@ class PolygonPoints(_PointSet):
         self.tensor[:, :, 0].clamp_(min=0, max=w)
         self.tensor[:, :, 1].clamp_(min=0, max=h)
 
+    def flatten(self):
+        """(N, 2V) view, what the evaluator hands to get_polygon_rles (pointset.py:253-257);
+        an empty set stays (0, V, 2) as in the reference."""
+        n = self.tensor.size(0)
+        return self.tensor if n == 0 else self.tensor.reshape(n, -1)
+
+    def get_box(self):
+        """(N,4) xyxy hull of the vertices (pointset.py:259-260)."""
+        return torch.cat([self.tensor.min(1)[0], self.tensor.max(1)[0]], dim=1)
+
     def __repr__(self):
         return "PolyPts(" + str(self.tensor) + ")"
 

@@ -19,4 +19,9 @@ for d in trace pmc1 pmc2 pmc3; do
     done
 done
 cp $OUT/*.json $OUT/*.err $KEEP/ 2>/dev/null || true
+python3 tools/prof_summary.py $KEEP/trace_*kernel_trace.csv > $KEEP/summary_trace.txt
+python3 tools/pmc_summary.py $KEEP/pmc1_*counter_collection.csv $KEEP/pmc1_*kernel_trace.csv > $KEEP/summary_pmc1.txt
+python3 tools/pmc_summary.py $KEEP/pmc2_*counter_collection.csv $KEEP/pmc2_*kernel_trace.csv > $KEEP/summary_pmc2.txt
+python3 tools/pmc_summary.py $KEEP/pmc3_*counter_collection.csv $KEEP/pmc3_*kernel_trace.csv > $KEEP/summary_pmc3.txt
+python3 tools/traffic_json.py $KEEP/pmc2_*counter_collection.csv $KEEP/pmc3_*counter_collection.csv $TAG $KEEP/hbm_traffic.json > /dev/null
 ls -la $KEEP
