@@ -27,6 +27,7 @@ SOURCES = [
     ("snake16.hip", []),
     ("featprep16.hip", []),
     ("raster.hip", ["-ffp-contract=off"]),
+    ("attender.hip", []),
 ]
 HEADERS = ["common.h", "sampling.h", "p16.h", os.path.join("..", "..", "include", "dance_hip.h")]
 

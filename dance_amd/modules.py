@@ -88,6 +88,40 @@ class _ConvNormAct(nn.Conv2d):
         return F.relu(x)
 
 
+class _AttConv(nn.Conv2d):
+    """Parameter holder with detectron2.layers.Conv2d's keys (`weight`, [`bias`], `norm.*`)."""
+
+    def __init__(self, cin, cout, norm):
+        super().__init__(cin, cout, kernel_size=3, stride=1, padding=1, bias=not norm)
+        self.norm = nn.GroupNorm(4, cout) if norm else None
+
+
+class Attender(nn.Sequential):
+    """Drop-in for `EdgeSnakeFPNHead.attender` (edge_det.py:66-100): same state-dict keys
+    (`0.weight`, `0.norm.weight`, ..., `2.bias`), `forward(1 - pred_edge) -> att_map`
+    (edge_det.py:202-204), run as three HIP launches (csrc/attender.hip).  GPU only."""
+
+    def __init__(self):
+        super().__init__(_AttConv(1, 32, True), _AttConv(32, 32, True), _AttConv(32, 1, False))
+        # edge_det.py:96-99 (c2_msra_fill = kaiming_normal_(fan_out, relu); the last conv N(0, 0.01), bias 0)
+        for m in (self[0], self[1]):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.normal_(self[2].weight, 0, 0.01)
+        nn.init.constant_(self[2].bias, 0)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("dance_amd.modules.Attender runs on a GPU only; there is no CPU fallback")
+        sig = (x.device,) + tuple(int(p._version) for p in self.parameters())
+        if getattr(self, "_att_sig", None) != sig:
+            f = lambda t: t.detach().float().contiguous()
+            self._att_w = (f(self[0].weight), f(self[0].norm.weight), f(self[0].norm.bias),
+                           f(self[1].weight.detach().permute(1, 2, 3, 0)), f(self[1].norm.weight),
+                           f(self[1].norm.bias), f(self[2].weight), f(self[2].bias))
+            self._att_sig = sig
+        return ops.attender(x, *self._att_w, eps=self[0].norm.eps)
+
+
 def _reference_init(module):
     # snake_head.py:632-641 / dsnake_head.py:255-259
     for m in module.modules():

@@ -273,3 +273,25 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
                                       None if last else ptr(x16), ptr(out) if last else None, b, c, h, w, st),
                   "gn_relu")
     return out
+
+
+# ---------------------------------------------------------------------------- attender
+def attender(x, w1, gn1_w, gn1_b, w2_packed, gn2_w, gn2_b, w3, b3, eps=1e-5):
+    """EdgeSnakeFPNHead.attender (edge_det.py:66-100) on x = 1 - pred_edge, (B,1,H,W) or (B,H,W)
+    -> attention map of the same shape.  w2_packed = attender.1.weight.permute(1,2,3,0)."""
+    _need_gpu(x, w1, w2_packed, w3)
+    shape = x.shape
+    if x.dim() == 4:
+        if x.size(1) != 1:
+            raise RuntimeError("attender: input must have one channel")
+        x = x[:, 0]
+    x = _f32c(x)
+    b, h, w = x.shape
+    att = torch.empty_like(x)
+    ws_bytes = lib().dance_attender_workspace_bytes(b, h, w)
+    ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().dance_attender(ptr(x), ptr(w1), ptr(gn1_w), ptr(gn1_b), ptr(w2_packed), ptr(gn2_w),
+                                   ptr(gn2_b), ptr(w3), ptr(b3), float(eps), ptr(att), ptr(ws), ws_bytes,
+                                   b, h, w, current_stream()), "attender")
+    return att.view(shape)

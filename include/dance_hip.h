@@ -95,6 +95,20 @@ int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamm
                   const float *beta, float eps, int groups, void *out16, float *out_nhwc,
                   int b, int c, int h, int w, void *stream);
 
+/* ------------------------------------ attention-map producer ------ */
+/* reference: EdgeSnakeFPNHead.attender, core/modeling/edge_snake/edge_det.py:66-100, applied
+ * at 200-204 to x = 1 - pred_edge: [Conv2d 3x3 pad 1 no bias -> GroupNorm(4,32) -> ReLU] for
+ * 1->32 and 32->32 channels, then Conv2d(32->1, 3x3, pad 1, bias) -> sigmoid.  fp32 FMA.
+ *   x (b,h,w) f32 (the reference's (b,1,h,w)); w1 (32,1,3,3), w3 (1,32,3,3) as in the
+ *   state-dict; w2_packed (32 cin, 3, 3, 32 cout) = attender.1.weight.permute(1,2,3,0);
+ *   gn*_w / gn*_b (32); b3 (1); att (b,h,w) f32 -- the attention plane the gather kernels
+ *   read (channel 0 of the snake head's input).  workspace: dance_attender_workspace_bytes. */
+int64_t dance_attender_workspace_bytes(int b, int h, int w);
+int dance_attender(const float *x, const float *w1, const float *gn1_w, const float *gn1_b,
+                   const float *w2_packed, const float *gn2_w, const float *gn2_b, const float *w3,
+                   const float *b3, float eps, float *att, void *workspace, int64_t workspace_bytes,
+                   int b, int h, int w, void *stream);
+
 /* --------------------------------------- polygon -> RLE mask ------ */
 /* reference call sites: get_polygon_rles = mask_util.merge(mask_util.frPyObjects([p.tolist()],
  * h, w)) per instance, on the CPU after a device -> host copy (core/evaluation/

@@ -369,20 +369,48 @@ def gen_bottom_out(sh):
     _save("g8_bottom_out", weight_seed=WEIGHT_SEED, weight_checksum=ck, feat_seed=31, out=x)
 
 
+def attender_inputs(seed):
+    """x = 1 - sigmoid(band-limited logits), the form the attender sees (edge_det.py:199-204):
+    a full-width map and a small odd-sized one."""
+    a = synthetic.make_smooth_features(2, 1, 50, 76, seed, attention=False, cell=4)
+    b = synthetic.make_smooth_features(1, 1, 37, 53, seed + 1, attention=False, cell=2)
+    return [1 - torch.sigmoid(3.0 * a), 1 - torch.sigmoid(3.0 * b)]
+
+
+def gen_attender():
+    """The reference's own EdgeSnakeFPNHead.attender (edge_det.py:66-100), built by the
+    reference's constructor, with seeded weights."""
+    from types import SimpleNamespace as NS
+    ed = ref_loader.load_edge_head()
+    shapes = {k: NS(stride=s, channels=256) for k, s in (("p2", 4), ("p3", 8), ("p4", 16), ("p5", 32))}
+    head = ed.EdgeSnakeFPNHead(ref_loader.edge_head_cfg(num_convs=0), shapes).eval()
+    sd = {k: v for k, v in head.attender.state_dict().items()}
+    ck = synthetic.fill_state_dict_(sd, WEIGHT_SEED)
+    head.attender.load_state_dict(sd)
+    out = {"weight_seed": WEIGHT_SEED, "weight_checksum": ck, "input_seed": 41}
+    with torch.no_grad():
+        for i, x in enumerate(attender_inputs(41)):
+            ref = head.attender(x)
+            _close(snake_ref.attender(sd, x, prefix=""), ref, 1e-6, "attender")
+            out["out%d" % i] = ref
+    _save("g9_attender", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_flush_denormal(False)
     extreme_utils_ref.build()
     sh, dh = ref_loader.load_reference()
-    gen_resampler(sh)
-    gen_gather(sh, dh)
-    gen_blocks(sh)
-    gen_snakenet(sh)
-    gen_dance(sh)
-    gen_dsnake(dh)
-    gen_upsample2x(sh)
-    gen_bottom_out(sh)
+    steps = {"resampler": lambda: gen_resampler(sh), "gather": lambda: gen_gather(sh, dh),
+             "blocks": lambda: gen_blocks(sh), "snakenet": lambda: gen_snakenet(sh),
+             "dance": lambda: gen_dance(sh), "dsnake": lambda: gen_dsnake(dh),
+             "upsample2x": lambda: gen_upsample2x(sh), "bottom_out": lambda: gen_bottom_out(sh),
+             "attender": gen_attender}
+    # `python -m oracle.gen_golden attender ...` regenerates only the named fixtures (floating-
+    # point fixtures move in the last bits with the host CPU's kernels: keep the committed ones)
+    for name in (sys.argv[1:] or list(steps)):
+        steps[name]()
     print("golden vectors written to", os.path.normpath(OUT))
 
 

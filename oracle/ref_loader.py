@@ -177,3 +177,53 @@ class FakeInstances:
 
     def has(self, name):
         return name in self._fields
+
+
+class _Registry:
+    """Placeholder for detectron2.utils.registry.Registry (register() decorator + get())."""
+
+    def __init__(self, name):
+        self._name, self._map = name, {}
+
+    def register(self, obj=None):
+        def deco(o):
+            self._map[o.__name__] = o
+            return o
+        return deco if obj is None else deco(obj)
+
+    def get(self, name):
+        return self._map[name]
+
+
+def load_edge_head():
+    """The reference's core/modeling/edge_snake/edge_det.py (EdgeSnakeFPNHead: scale heads,
+    edge predictor, attender, refine head), loaded from /root/reference as a member of a
+    placeholder package so that its `from .snake_head import RefineNet` resolves to the
+    reference's own snake_head.py."""
+    if "edge" in _loaded:
+        return _loaded["edge"]
+    snake, _ = load_reference()
+    sys.modules["detectron2.layers"].ShapeSpec = NS
+    _module("detectron2.utils")
+    _module("detectron2.utils.registry", Registry=_Registry)
+    _module("detectron2.structures", Instances=FakeInstances, Boxes=FakeBoxes)
+    sys.modules["fvcore.nn.weight_init"].c2_msra_fill = lambda m: None     # weights are seeded afterwards
+    sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
+    sys.modules["core.layers"].DiceLoss = lambda *a, **k: None             # training only
+    pkg = _module("_dance_ref_edge_pkg")
+    pkg.__path__ = []
+    sys.modules["_dance_ref_edge_pkg.snake_head"] = snake
+    _loaded["edge"] = _load("_dance_ref_edge_pkg.edge_det", REF + "/core/modeling/edge_snake/edge_det.py")
+    return _loaded["edge"]
+
+
+def edge_head_cfg(**snake_over):
+    """dance_cfg() plus the keys EdgeSnakeFPNHead.__init__ reads (edge_det.py:40-64, 102-104;
+    values: configs/Base-dance.yaml + core/config/defaults.py)."""
+    cfg = dance_cfg(**snake_over)
+    eh = cfg.MODEL.EDGE_HEAD
+    eh.NAME, eh.IN_FEATURES, eh.IGNORE_VALUE, eh.NUM_CLASSES = "EdgeSnakeFPNHead", ["p2", "p3", "p4", "p5"], 255, 1
+    eh.COMMON_STRIDE, eh.LOSS_WEIGHT, eh.BCE_WEIGHT, eh.TRAIN, eh.STRONG_FEAT = 4, 1.0, 0.0, True, True
+    cfg.MODEL.SNAKE_HEAD.EDGE_IN_TH = -1.0
+    cfg.TEST = NS(GT_IN=NS(ON=False, WHAT=("instance",)))
+    return cfg

@@ -127,6 +127,19 @@ def bottom_out(sd_all, features, groups=32, eps=1e-5):
     return x
 
 
+def attender(sd_all, x, prefix="attender.", eps=1e-5):
+    """EdgeSnakeFPNHead.attender, edge_det.py:66-100, applied as at 202-204 to x = 1 - pred_edge
+    (B,1,H,W): Conv2d(1->32, 3x3, pad 1, no bias) -> GroupNorm(4,32) -> ReLU, the same 32->32,
+    then Conv2d(32->1, 3x3, pad 1, bias) -> sigmoid.  Returns the attention map (B,1,H,W)."""
+    import torch.nn.functional as F
+    for i in (0, 1):
+        x = F.conv2d(x, sd_all[prefix + "%d.weight" % i], None, padding=1)
+        x = F.group_norm(x, 4, sd_all[prefix + "%d.norm.weight" % i], sd_all[prefix + "%d.norm.bias" % i], eps)
+        x = F.relu(x)
+    x = F.conv2d(x, sd_all[prefix + "2.weight"], sd_all[prefix + "2.bias"], padding=1)
+    return torch.sigmoid(x)
+
+
 # ------------------------------------------------------------------------------- gather
 def get_locations_feature(features, locations, image_idx, padding_mode):
     """snake_head.py:1542-1578 (padding_mode="reflection") and dsnake_head.py:670-695

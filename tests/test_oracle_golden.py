@@ -124,6 +124,21 @@ def test_dsnake_restatement():
         assert rel_err(out["preds"][i], g["pred%d" % i]) < 1e-5
 
 
+def test_attender_restatement():
+    """oracle/snake_ref.attender against the output of the reference's own
+    EdgeSnakeFPNHead.attender (edge_det.py:66-100; fixture written by oracle/gen_golden.py)."""
+    from dance_amd import modules
+    g = golden("g9_attender")
+    sd = {k: v.clone() for k, v in modules.Attender().state_dict().items()}
+    ck = synthetic.fill_state_dict_(sd, int(g["weight_seed"]))
+    assert abs(ck - float(g["weight_checksum"])) < 1e-6 * ck
+    seed = int(g["input_seed"])
+    a = synthetic.make_smooth_features(2, 1, 50, 76, seed, attention=False, cell=4)
+    b = synthetic.make_smooth_features(1, 1, 37, 53, seed + 1, attention=False, cell=2)
+    for i, x in enumerate([1 - torch.sigmoid(3.0 * a), 1 - torch.sigmoid(3.0 * b)]):
+        assert float((snake_ref.attender(sd, x, prefix="") - g["out%d" % i]).abs().max()) < 1e-6
+
+
 def test_upsample2x_restatement():
     g = golden("g7_upsample2x")
     for i in range(3):
