@@ -272,6 +272,44 @@ def main():
                          "frac_of_f16_peak": 3 * fp_flops / hip_ms / 1e9 / PEAK_F16_MFMA_TFLOPS,
                          "stock_torch_ms": stock_ms, "speedup_vs_stock": stock_ms / hip_ms}
             del net2, layers
+        # the attention-map producer in front of the path: EdgeSnakeFPNHead.attender
+        # (edge_det.py:66-100, 200-204) on the batch's (b,1,200,304) edge maps, HIP vs stock torch.nn
+        att_mod = modules.Attender()
+        sd_a = {k: t.clone() for k, t in att_mod.state_dict().items()}
+        synthetic.fill_state_dict_(sd_a, 1234)
+        att_mod.load_state_dict(sd_a)
+        att_mod = att_mod.to(dev).eval()
+        edge_in = (1 - feats[:, :1]).contiguous()
+
+        def stock_att():
+            x = edge_in
+            for i in (0, 1):
+                x = torch.relu(torch.nn.functional.group_norm(
+                    torch.nn.functional.conv2d(x, att_mod[i].weight, None, padding=1), 4,
+                    att_mod[i].norm.weight, att_mod[i].norm.bias, 1e-5))
+            return torch.sigmoid(torch.nn.functional.conv2d(x, att_mod[2].weight, att_mod[2].bias, padding=1))
+
+        def timed2(fn, reps):
+            for _ in range(2):
+                fn()
+            g0.record()
+            for _ in range(reps):
+                fn()
+            g1.record()
+            torch.cuda.synchronize()
+            return g0.elapsed_time(g1) / reps
+
+        with torch.no_grad():
+            att_ms, att_stock_ms = timed2(lambda: att_mod(edge_in), 10), timed2(stock_att, 5)
+            att_err = float((att_mod(edge_in) - stock_att()).abs().max())
+        attender_fig = {"stage": "attender: 3 x conv3x3 (1->32->32->1) + 2 x GroupNorm(4,32) + ReLU + sigmoid on "
+                                 "(%d,1,%d,%d); outside the timed step" % (b, HF, WF),
+                        "kernel": "k_att_stats1 + k_att_conv2 + k_att_out (fp32 FMA)", "ms": att_ms,
+                        "algorithmic_TFLOPs": 2.0 * (288 + 9216 + 288) * HF * WF * b / att_ms / 1e9,
+                        "stock_torch_ms": att_stock_ms, "speedup_vs_stock": att_stock_ms / att_ms,
+                        "max_abs_diff_vs_stock": att_err}
+        del att_mod
+
         # the step after the path: deformed contours -> RLE masks, the
         # reference's get_polygon_rles (coco_evaluation.py:311-318; one pycocotools call per
         # instance on the host there).  Contours clipped to the image as postprocessing does.
@@ -403,6 +441,7 @@ def main():
             "streams": args.streams,
             "feat_prep": feat_prep,
             "mask_rle": mask_rle,
+            "attender": attender_fig,
             "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,
                                  "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),
                                  "note": "reference scope `contour_sampling`, outside the timed step"},

@@ -12,7 +12,7 @@
 //                 packing), raw output (B,32,H,W) + group sums;
 //   k_att_out     per tile: GN2 -> ReLU of the raw output with halo into LDS, conv3 + bias ->
 //                 sigmoid -> the attention plane the gather kernels read.
-// Group sums are fp32 per thread -> wave shuffle -> fp64 atomics (as featprep16.hip).
+// Group sums are fp32 per thread -> wave shuffle -> workgroup (LDS) -> one fp64 atomic per value.
 #include "common.h"
 
 using dance::launch_check;
@@ -31,28 +31,44 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// (sum, sum of squares) of 32 channel values per lane -> 4 groups -> wave -> fp64 atomics
-__device__ __forceinline__ void group_stats(const float (&y)[AT_C], bool valid, double *st, int lane)
-{
+// Per-lane (sum, sum of squares) of the 4 channel groups, accumulated over a thread's pixels.
+struct GroupSums {
+    float s1[AT_G], s2[AT_G];
+    __device__ __forceinline__ void clear()
+    {
 #pragma unroll
-    for (int g = 0; g < AT_G; ++g) {
-        float s1 = 0.f, s2 = 0.f;
-        if (valid) {
+        for (int g = 0; g < AT_G; ++g)
+            s1[g] = s2[g] = 0.f;
+    }
+    __device__ __forceinline__ void add(const float (&y)[AT_C])
+    {
+#pragma unroll
+        for (int g = 0; g < AT_G; ++g)
 #pragma unroll
             for (int i = 0; i < AT_C / AT_G; ++i) {
                 const float v = y[g * (AT_C / AT_G) + i];
-                s1 += v;
-                s2 = fmaf(v, v, s2);
+                s1[g] += v;
+                s2[g] = fmaf(v, v, s2[g]);
+            }
+    }
+    // lanes -> wave (shuffles) -> workgroup (LDS, red: 4 x 8 floats) -> ONE fp64 atomic per value
+    // and workgroup: thousands of same-address atomics from every wave serialise in the L2
+    __device__ __forceinline__ void flush(double *st, float *red, int t)
+    {
+        const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+        for (int g = 0; g < AT_G; ++g) {
+            const float a = wave_sum(s1[g]), b = wave_sum(s2[g]);
+            if (lane == 0) {
+                red[wave * 8 + 2 * g] = a;
+                red[wave * 8 + 2 * g + 1] = b;
             }
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0) {
-            atomicAdd(st + 2 * g, (double)s1);
-            atomicAdd(st + 2 * g + 1, (double)s2);
-        }
+        __syncthreads();
+        if (t < 8)
+            atomicAdd(st + t, (double)red[t] + (double)red[8 + t] + (double)red[16 + t] + (double)red[24 + t]);
     }
-}
+};
 
 // GroupNorm as a per-channel affine a*x + b from the accumulated sums
 __device__ __forceinline__ void gn_affine(const double *st, const float *gamma, const float *beta, double cnt,
@@ -72,16 +88,22 @@ __device__ __forceinline__ float px(const float *x, int h, int w, int yy, int xx
     return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? x[(long long)yy * w + xx] : 0.f;
 }
 
+constexpr int AT_PPT = 8;                                       // pixels per thread in k_att_stats1
+
 __global__ __launch_bounds__(256) void k_att_stats1(const float *__restrict__ x, const float *__restrict__ w1,
                                                     double *__restrict__ stats1, int h, int w)
 {
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = p < h * w;
+    __shared__ float red[32];
+    const int b = blockIdx.y;
     const float *xb = x + (long long)b * h * w;
-    float y[AT_C];
-    if (valid) {
+    GroupSums gs;
+    gs.clear();
+    for (int k = 0; k < AT_PPT; ++k) {
+        const int p = (blockIdx.x * AT_PPT + k) * 256 + threadIdx.x;
+        if (p >= h * w)
+            break;
         const int yy = p / w, xx = p - yy * w;
-        float nb[9];
+        float nb[9], y[AT_C];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             nb[t] = px(xb, h, w, yy + t / 3 - 1, xx + t % 3 - 1);
@@ -93,8 +115,9 @@ __global__ __launch_bounds__(256) void k_att_stats1(const float *__restrict__ x,
                 s = fmaf(w1[o * 9 + t], nb[t], s);
             y[o] = s;
         }
+        gs.add(y);
     }
-    group_stats(y, valid, stats1 + (long long)b * AT_G * 2, threadIdx.x & 63);
+    gs.flush(stats1 + (long long)b * AT_G * 2, red, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, const float *__restrict__ w1,
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, 
 {
     __shared__ float xt[AT_XY][AT_XX];
     __shared__ float act[AT_C][AT_HY][AT_HX];
-    __shared__ float ga[AT_C], gb[AT_C];
+    __shared__ float ga[AT_C], gb[AT_C], red[32];
     const int b = blockIdx.z, x0 = blockIdx.x * AT_TX, y0 = blockIdx.y * AT_TY;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     const float *xb = x + (long long)b * h * w;
@@ -116,19 +139,35 @@ __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, 
     if (t < AT_C)
         gn_affine(stats1 + (long long)b * AT_G * 2, g1, b1, (double)(AT_C / AT_G) * h * w, eps, t, ga[t], gb[t]);
     __syncthreads();
-    // layer 1 on the halo tile: conv1 -> GN1 -> ReLU; zero outside the image (conv2's padding)
-    for (int i = t; i < AT_C * AT_HY * AT_HX; i += 256) {
-        const int c = i / (AT_HY * AT_HX), rem = i - c * (AT_HY * AT_HX), r = rem / AT_HX, q = rem - r * AT_HX;
-        const int yy = y0 + r - 1, xx = x0 + q - 1;
-        float v = 0.f;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-            float s = 0.f;
+    // layer 1 on the halo tile: conv1 -> GN1 -> ReLU; zero outside the image (conv2's padding).
+    // A thread keeps the 3x3 input patch of its (up to two) tile positions in registers and
+    // walks the channels with uniform (scalar) weights.
+    {
+        constexpr int NPOS = AT_HY * AT_HX, ROUNDS = (NPOS + 255) / 256;
+        float nb[ROUNDS][9];
+        bool in[ROUNDS];
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int pos = min(t + j * 256, NPOS - 1), r = pos / AT_HX, q = pos - r * AT_HX;
+            const int yy = y0 + r - 1, xx = x0 + q - 1;
+            in[j] = yy >= 0 && yy < h && xx >= 0 && xx < w;
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                s = fmaf(w1[c * 9 + k], xt[r + k / 3][q + k % 3], s);
-            v = fmaxf(fmaf(s, ga[c], gb[c]), 0.f);
+                nb[j][k] = xt[r + k / 3][q + k % 3];
         }
-        act[c][r][q] = v;
+#pragma unroll 2
+        for (int c = 0; c < AT_C; ++c) {
+            const float a = ga[c], bb = gb[c];
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    s = fmaf(w1[c * 9 + k], nb[j][k], s);
+                if (t + j * 256 < NPOS)
+                    (&act[c][0][0])[t + j * 256] = in[j] ? fmaxf(fmaf(s, a, bb), 0.f) : 0.f;
+            }
+        }
     }
     __syncthreads();
     float acc[AT_C];
@@ -156,7 +195,11 @@ __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, 
         for (int o = 0; o < AT_C; ++o)
             dst[(long long)o * h * w] = acc[o];
     }
-    group_stats(acc, valid, stats2 + (long long)b * AT_G * 2, t & 63);
+    GroupSums gs;
+    gs.clear();
+    if (valid)
+        gs.add(acc);
+    gs.flush(stats2 + (long long)b * AT_G * 2, red, t);
 }
 
 __global__ __launch_bounds__(256) void k_att_out(const float *__restrict__ y2, const float *__restrict__ g2,
@@ -221,7 +264,7 @@ extern "C" int dance_attender(const float *x, const float *w1, const float *gn1_
     if (e != hipSuccess)
         return dance::fail((int)e, __func__, hipGetErrorString(e));
     const dim3 tiles(dance::ceil_div(w, AT_TX), dance::ceil_div(h, AT_TY), b);
-    hipLaunchKernelGGL(k_att_stats1, dim3(dance::ceil_div(h * w, 256), b), dim3(256), 0, s, x, w1, stats1, h, w);
+    hipLaunchKernelGGL(k_att_stats1, dim3(dance::ceil_div(h * w, 256 * AT_PPT), b), dim3(256), 0, s, x, w1, stats1, h, w);
     hipLaunchKernelGGL(k_att_conv2, tiles, dim3(256), 0, s, x, w1, gn1_w, gn1_b, stats1, w2_packed, y2, stats2, eps,
                        h, w);
     hipLaunchKernelGGL(k_att_out, tiles, dim3(256), 0, s, y2, gn2_w, gn2_b, stats2, w3, b3, att, eps, h, w);
