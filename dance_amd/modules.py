@@ -270,7 +270,12 @@ class RefineNet(_SnakeHeadBase):
         """Attention split (snake_head.py:1812-1814) + bottom_out (1816-1820) ->
         (feat NHWC, att plane); the re-concatenation of :1824 is never materialised."""
         d = self._get_deformer()
-        if self.attention:
+        if isinstance(features, (tuple, list)):
+            # (att_map (B,1,Hf,Wf), x (B,C,Hf,Wf)) from EdgeSnakeFPNHead below: the reference's
+            # torch.cat([att_map, x]) (edge_det.py:313-315) and this split cancel out
+            att, feats, c_off = features[0][:, 0].contiguous(), features[1], 0
+            features = feats
+        elif self.attention:
             att, feats, c_off = features[:, 0].contiguous(), features[:, 1:], 1
         else:
             att, feats, c_off = None, features, 0
@@ -445,3 +450,86 @@ class DsnakeHead(_SnakeHeadBase):
         self.last_stages = {"init": init_locations, "exts_raw": pred_exts, "exts": exts,
                             "octagons": locations, "preds": preds}
         return results, {}
+
+
+# ------------------------------------------------------------- the heads' callers (L5)
+class EdgeSnakeFPNHead(nn.Module):
+    """Drop-in for the reference's `EdgeSnakeFPNHead` (core/modeling/edge_snake/edge_det.py:35-395),
+    inference path of the shipped configurations (EDGE_HEAD.TRAIN, STRONG_FEAT, SNAKE_HEAD.ATTENTION):
+
+        x = sum_f scale_heads[f](features[f])                 edge_det.py:188-194   (stock torch.nn)
+        pred_edge = sigmoid(predictor(x))                     :197-199              (stock torch.nn)
+        att_map = attender(1 - pred_edge)                     :200-204              (HIP, Attender)
+        refine_head(cat([att_map, x]), pred_instances, None)  :313-315, 387         (HIP, RefineNet)
+        return att_map, {}, new_instances                     :392-395
+
+    Same constructor `(cfg, input_shape)` and state-dict keys (`attender.*`, `p2.0.*` ... `p5.4.*`,
+    `predictor.*`, `refine_head.*`).  The semantic-FPN 2-D convolutions stay stock PyTorch-ROCm
+    (boundary / caller); the concatenation is not materialised."""
+
+    def __init__(self, cfg, input_shape, polygon_cls=PolygonPoints):
+        super().__init__()
+        eh, sh = cfg.MODEL.EDGE_HEAD, cfg.MODEL.SNAKE_HEAD
+        self.in_features = list(eh.IN_FEATURES)
+        self.common_stride = eh.COMMON_STRIDE
+        self.attention = bool(getattr(sh, "ATTENTION", False))
+        self.strong_feat = bool(getattr(eh, "STRONG_FEAT", False))
+        self.edge_on = bool(getattr(eh, "TRAIN", True))
+        conv_dims, norm = eh.CONVS_DIM, getattr(eh, "NORM", "GN")
+        gt_in = getattr(getattr(cfg, "TEST", None), "GT_IN", None)
+        refused = {k: v for k, v in (("SNAKE_HEAD.EDGE_IN", getattr(sh, "EDGE_IN", False)),
+                                     ("SNAKE_HEAD.SELECTIVE_REFINE", getattr(sh, "SELECTIVE_REFINE", False)),
+                                     ("TEST.GT_IN.ON", bool(gt_in is not None and getattr(gt_in, "ON", False))),
+                                     ("EDGE_HEAD.TRAIN off", not self.edge_on)) if v}
+        if refused:
+            raise NotImplementedError("EdgeSnakeFPNHead options outside the built path: %s" % refused)
+        import math
+        if self.attention:                                                  # edge_det.py:66-100
+            self.attender = Attender()
+        self.scale_heads = []
+        for f in self.in_features:                                          # edge_det.py:106-138
+            stride, cin = input_shape[f].stride, input_shape[f].channels
+            ops_ = []
+            for k in range(max(1, int(math.log2(stride) - math.log2(self.common_stride)))):
+                ops_.append(_ConvNormAct(cin if k == 0 else conv_dims, conv_dims, 1, norm if norm == "GN" else ""))
+                if stride != self.common_stride:
+                    ops_.append(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+            self.scale_heads.append(nn.Sequential(*ops_))
+            self.add_module(f, self.scale_heads[-1])
+        num_classes = eh.NUM_CLASSES
+        if not self.strong_feat:                                            # edge_det.py:140-163
+            self.predictor = nn.Conv2d(conv_dims, num_classes, kernel_size=1)
+        else:
+            self.predictor = nn.Sequential(_ConvNormAct(conv_dims, conv_dims, 1, norm if norm == "GN" else ""),
+                                           nn.Conv2d(conv_dims, num_classes, kernel_size=1))
+        self.refine_head = RefineNet(cfg, polygon_cls=polygon_cls)
+
+    def forward(self, features, pred_instances=None, targets=None):
+        if self.training:
+            raise NotImplementedError("dance_amd.EdgeSnakeFPNHead is inference-only (call .eval())")
+        with timer.env("pfpn_back"):
+            x = None
+            for f, head in zip(self.in_features, self.scale_heads):
+                y = head(features[f])
+                x = y if x is None else x + y
+        with timer.env("edge"):
+            pred_edge = self.predictor(x).sigmoid()
+            att_map = self.attender(1 - pred_edge) if self.attention else None
+        feats = x if self.strong_feat else features["p2"]
+        snake_input = (att_map, feats) if self.attention else feats
+        new_instances, _ = self.refine_head(snake_input, pred_instances, None)
+        return (att_map if self.attention else pred_edge), {}, new_instances
+
+
+class SnakeFPNHead(nn.Module):
+    """Drop-in for the deep-snake baseline's caller (dsnake_head.py:182-194)."""
+
+    def __init__(self, cfg, input_shape=None, polygon_cls=PolygonPoints, extreme_cls=ExtremePoints):
+        super().__init__()
+        self.refine_head = DsnakeHead(cfg, polygon_cls=polygon_cls, extreme_cls=extreme_cls)
+
+    def forward(self, features, pred_instances=None, targets=None):
+        if self.training:
+            raise NotImplementedError("dance_amd.SnakeFPNHead is inference-only (call .eval())")
+        new_instances, _ = self.refine_head(features["p2"], pred_instances, None)
+        return {}, new_instances

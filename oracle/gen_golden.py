@@ -396,6 +396,44 @@ def gen_attender():
     _save("g9_attender", **out)
 
 
+EDGE_HEAD_LEVELS = (("p2", 4), ("p3", 8), ("p4", 16), ("p5", 32))
+
+
+def edge_head_inputs(seed, hf=48, wf=64, n=6):
+    """Band-limited FPN levels p2..p5 of one (4*hf) x (4*wf) image and n detector boxes."""
+    feats = {}
+    for i, (name, stride) in enumerate(EDGE_HEAD_LEVELS):
+        k = stride // 4
+        feats[name] = synthetic.make_smooth_features(1, 256, hf // k, wf // k, seed + i, attention=False,
+                                                     cell=max(2, 8 // k))
+    boxes = synthetic.make_boxes(n, hf * 4, wf * 4, seed + 9, r_min=10, r_max=50)
+    return feats, boxes
+
+
+def gen_edge_head():
+    """The reference's own EdgeSnakeFPNHead.forward (edge_det.py:187-395) in eval mode on one
+    image: scale heads -> predictor -> attender -> RefineNet.single_test; shipped configuration
+    (attention, strong features, box initial contours, NUM_CONVS 2), 128 vertices."""
+    from types import SimpleNamespace as NS
+    ed = ref_loader.load_edge_head()
+    shapes = {k: NS(stride=s, channels=256) for k, s in EDGE_HEAD_LEVELS}
+    cfg = ref_loader.edge_head_cfg(num_convs=2, num_sampling=128)
+    head = ed.EdgeSnakeFPNHead(cfg, shapes).eval()
+    sd = head.state_dict()
+    ck = synthetic.fill_state_dict_(sd, WEIGHT_SEED)
+    head.load_state_dict(sd)
+    feats, boxes = edge_head_inputs(51)
+    inst = ref_loader.FakeInstances((192, 256), pred_boxes=ref_loader.FakeBoxes(boxes.clone()))
+    with torch.no_grad():
+        att, _, new = head(feats, [inst], None)
+    polys = new[0].pred_polys.tensor
+    mine_att, mine = snake_ref.edge_head_forward({k: v for k, v in sd.items()}, feats, boxes, (192, 256), 128)
+    _close(mine_att, att, 1e-5, "edge head attention map")
+    _close(mine[-1], polys, 1e-4, "edge head contours")
+    _save("g10_edge_head", weight_seed=WEIGHT_SEED, weight_checksum=ck, input_seed=51, att_map=att,
+          pred_polys=polys)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -406,7 +444,7 @@ def main():
              "blocks": lambda: gen_blocks(sh), "snakenet": lambda: gen_snakenet(sh),
              "dance": lambda: gen_dance(sh), "dsnake": lambda: gen_dsnake(dh),
              "upsample2x": lambda: gen_upsample2x(sh), "bottom_out": lambda: gen_bottom_out(sh),
-             "attender": gen_attender}
+             "attender": gen_attender, "edge_head": gen_edge_head}
     # `python -m oracle.gen_golden attender ...` regenerates only the named fixtures (floating-
     # point fixtures move in the last bits with the host CPU's kernels: keep the committed ones)
     for name in (sys.argv[1:] or list(steps)):

@@ -140,6 +140,43 @@ def attender(sd_all, x, prefix="attender.", eps=1e-5):
     return torch.sigmoid(x)
 
 
+def edge_head_forward(sd, features, boxes, image_size, num_sampling, in_features=("p2", "p3", "p4", "p5"),
+                      strides=(4, 8, 16, 32), common_stride=4):
+    """EdgeSnakeFPNHead.forward, inference, one image, shipped configuration (edge_det.py:187-204,
+    313-315, 387-395 -> RefineNet.single_test snake_head.py:1763-1869 with INITIAL "box"):
+    semantic-FPN scale heads summed -> predictor -> sigmoid -> attender(1 - edge) -> bottom_out ->
+    3 attentive deformation iterations.  sd = the head's state-dict; features = {"p2": ...};
+    boxes (N,4).  Returns (att_map (1,1,Hf,Wf), [contours (N,V,2)] * 3)."""
+    import math
+    import torch.nn.functional as F
+
+    def cna(x, prefix):
+        x = F.conv2d(x, sd[prefix + "weight"], None, padding=1)
+        return F.relu(F.group_norm(x, 32, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-5))
+
+    x = None
+    for f, stride in zip(in_features, strides):
+        y, idx = features[f], 0
+        for _ in range(max(1, int(math.log2(stride) - math.log2(common_stride)))):
+            y = cna(y, "%s.%d." % (f, idx))
+            idx += 1
+            if stride != common_stride:
+                y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=False)
+                idx += 1
+        x = y if x is None else x + y
+    logits = F.conv2d(cna(x, "predictor.0."), sd["predictor.1.weight"], sd["predictor.1.bias"])
+    att_map = attender(sd, 1 - torch.sigmoid(logits))
+    rsd = sub_state_dict(sd, "refine_head.")
+    boxes = boxes.clone()
+    h, w = image_size
+    init, _ = uniform_upsample(box_polygon(boxes)[None], num_sampling)
+    boxes[:, 0::2].clamp_(0, w)
+    boxes[:, 1::2].clamp_(0, h)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], dim=1)
+    feats = torch.cat([att_map, bottom_out(rsd, x)], dim=1)
+    return att_map, dance_deform(rsd, feats, init, None, image_size, whs)
+
+
 # ------------------------------------------------------------------------------- gather
 def get_locations_feature(features, locations, image_idx, padding_mode):
     """snake_head.py:1542-1578 (padding_mode="reflection") and dsnake_head.py:670-695

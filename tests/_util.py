@@ -91,3 +91,32 @@ class FakeInstances:
 
     def has(self, name):
         return name in self._fields
+
+
+EDGE_HEAD_LEVELS = (("p2", 4), ("p3", 8), ("p4", 16), ("p5", 32))
+
+
+def edge_head_cfg(num_sampling=128, num_convs=2):
+    """A yacs-shaped namespace with the keys EdgeSnakeFPNHead / RefineNet read, set as
+    configs/Dance_R_50_3x.yaml + Base-dance.yaml + core/config/defaults.py set them."""
+    from types import SimpleNamespace as NS
+    snake = NS(CONV_TYPE="ccn", FEAT_DIM=128, NUM_ITER=(0, 0, 1), NUM_CONVS=num_convs, NUM_LAYER=(8, 8, 8),
+               CIR_DILATIONS=((1, 1, 1, 2, 2, 4, 4),) * 3, DILATIONS=(1, 1), NUM_SAMPLING=num_sampling,
+               INITIAL="box", DE_LOC_TYPE="derange", INDIVIDUAL_SCALE=True, ATTENTION=True, DETACH=True,
+               VIS_PATH=False, EDGE_IN=False, SELECTIVE_REFINE=False)
+    edge = NS(NAME="EdgeSnakeFPNHead", IN_FEATURES=["p2", "p3", "p4", "p5"], NUM_CLASSES=1, CONVS_DIM=256,
+              COMMON_STRIDE=4, NORM="GN", TRAIN=True, STRONG_FEAT=True)
+    shapes = {k: NS(stride=s, channels=256) for k, s in EDGE_HEAD_LEVELS}
+    return NS(MODEL=NS(EDGE_HEAD=edge, SNAKE_HEAD=snake), TEST=NS(GT_IN=NS(ON=False, WHAT=("instance",)))), shapes
+
+
+def edge_head_inputs(seed, hf=48, wf=64, n=6):
+    """Same construction as oracle/gen_golden.edge_head_inputs."""
+    from dance_amd import synthetic
+    feats = {}
+    for i, (name, stride) in enumerate(EDGE_HEAD_LEVELS):
+        k = stride // 4
+        feats[name] = synthetic.make_smooth_features(1, 256, hf // k, wf // k, seed + i, attention=False,
+                                                     cell=max(2, 8 // k))
+    boxes = synthetic.make_boxes(n, hf * 4, wf * 4, seed + 9, r_min=10, r_max=50)
+    return feats, boxes

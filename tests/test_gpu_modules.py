@@ -108,3 +108,43 @@ def test_timer_scopes_match_the_reference_names(device):
     assert set(stats) == {"contour_sampling", "snake_feat_prep", "snake_deformation", "snake_postprocess"}
     assert all(ms >= 0.0 and n == 1 for ms, n in stats.values())
     assert stats["snake_deformation"][0] > stats["contour_sampling"][0]
+
+
+def test_edge_snake_fpn_head_end_to_end(device):
+    """The reference's EdgeSnakeFPNHead.forward (edge_det.py:187-395) on one image: stock torch
+    scale heads + predictor, HIP attender, HIP feature prep + contour path; against the golden
+    output of the reference's own module (tests/golden/g10_edge_head.npz)."""
+    from _util import coord_rel_err, edge_head_cfg, edge_head_inputs, golden
+    g = golden("g10_edge_head")
+    cfg, shapes = edge_head_cfg()
+    head = modules.EdgeSnakeFPNHead(cfg, shapes)
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    ck = synthetic.fill_state_dict_(sd, int(g["weight_seed"]))
+    assert abs(ck - float(g["weight_checksum"])) < 1e-6 * ck
+    head.load_state_dict(sd)
+    head = head.to(device).eval()
+    feats, boxes = edge_head_inputs(int(g["input_seed"]))
+    inst = FakeInstances((192, 256), pred_boxes=FakeBoxes(boxes.clone().to(device)))
+    with torch.no_grad():
+        att, losses, new = head({k: v.to(device) for k, v in feats.items()}, [inst], None)
+    assert losses == {} and att.shape == (1, 1, 48, 64)
+    assert float((att.cpu() - g["att_map"]).abs().max()) < 1e-4
+    polys = new[0].pred_polys.tensor
+    assert polys.shape == (6, 128, 2)
+    assert coord_rel_err(polys, g["pred_polys"]) < 1e-4
+    # masks of the result, the reference evaluator's next step (coco_evaluation.py:352-357)
+    from dance_amd import rle
+    from oracle import rle_ref
+    new[0].pred_polys.clip((192, 256))
+    got = rle.get_polygon_rles(new[0].pred_polys.flatten(), (192, 256))
+    want = rle_ref.get_polygon_rles(new[0].pred_polys.flatten().cpu().numpy(), (192, 256))
+    assert got == want and len(got) == 6
+
+
+def test_snake_fpn_head_is_the_dsnake_caller(device):
+    """dsnake_head.py:182-194: SnakeFPNHead hands features["p2"] to DsnakeHead."""
+    cfg = config.dsnake_r50(num_convs=0)
+    head = modules.SnakeFPNHead(cfg).to(device).eval()
+    assert [k for k in head.state_dict()][0].startswith("refine_head.")
+    with pytest.raises(NotImplementedError):
+        head.train()({"p2": None}, None, None)

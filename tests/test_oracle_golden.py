@@ -139,6 +139,22 @@ def test_attender_restatement():
         assert float((snake_ref.attender(sd, x, prefix="") - g["out%d" % i]).abs().max()) < 1e-6
 
 
+def test_edge_head_restatement():
+    """oracle/snake_ref.edge_head_forward against the reference's own EdgeSnakeFPNHead.forward
+    (edge_det.py:187-395, eval, one image; fixture written by oracle/gen_golden.py)."""
+    from _util import coord_rel_err, edge_head_cfg, edge_head_inputs
+    from dance_amd import modules
+    g = golden("g10_edge_head")
+    cfg, shapes = edge_head_cfg()
+    sd = {k: v.clone() for k, v in modules.EdgeSnakeFPNHead(cfg, shapes).state_dict().items()}
+    ck = synthetic.fill_state_dict_(sd, int(g["weight_seed"]))
+    assert abs(ck - float(g["weight_checksum"])) < 1e-6 * ck, "state-dict keys/order differ from the reference's"
+    feats, boxes = edge_head_inputs(int(g["input_seed"]))
+    att, preds = snake_ref.edge_head_forward(sd, feats, boxes, (192, 256), 128)
+    assert float((att - g["att_map"]).abs().max()) < 1e-5
+    assert coord_rel_err(preds[-1], g["pred_polys"]) < 1e-4
+
+
 def test_upsample2x_restatement():
     g = golden("g7_upsample2x")
     for i in range(3):
