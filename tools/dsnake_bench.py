@@ -1,8 +1,9 @@
 """BASELINE config 4 (Dsnake R50, 32 images x 100 instances) through the drop-in module:
 init (V=40) -> extreme points -> octagon -> 3 evolves; wall time per forward."""
-import sys, time, torch
-sys.path.insert(0, '.')
-sys.path.insert(0, 'tests')
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from _util import FakeBoxes, FakeInstances
 from dance_amd import config, modules, synthetic
 dev = torch.device('cuda')
