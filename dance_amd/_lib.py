@@ -93,6 +93,7 @@ SIGNATURES = {
                              c_int, c_int, P]),
     "dance_gather_head16": (c_int, [P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_xin_head16": (c_int, [P, c_int64, P, P, c_float, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int, P]),
     "dance_snake_evolve16": (c_int, [POINTER(SnakeNet16Struct), POINTER(SnakeNetStruct), P, P, P, P, P,
                                      P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -928,10 +928,12 @@ struct Gather16Args {
     const int *image_idx;
     float *att_out;
     int b, hf, wf, c, reflection, deloc;
+    const float *x_in;          // XIN flavour: precomputed (c + 2, v) fp32 input per contour instead of
+    long long x_stride;         // the gather (Dsnake init: fused features + de_location channels)
 };
 
-template <int RT, int TERMS>
-__global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16Args g)
+template <int RT, int TERMS, bool XIN>
+__device__ __forceinline__ void gather_head16_body(const Conv16Args &a, const Gather16Args &g)
 {
     constexpr int CBC = 8;                                      // 64 channels per chunk
     using G = Geo<RT, CBC>;
@@ -955,9 +957,16 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
     img = img_ok ? img : 0;
     const long long plane = (long long)g.hf * g.wf;
 
+    const float *xn = XIN ? g.x_in + nn * g.x_stride : nullptr;
     float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
-    if (g.deloc != DANCE_DELOC_NONE)
+    if (!XIN && g.deloc != DANCE_DELOC_NONE)
         dance::contour_bounds(loc_n, v, red, xmin, xmax, ymin, ymax);
+    if constexpr (XIN) {
+        for (int vi = t; vi < v; vi += 256) {
+            dl[vi] = xn[(long long)g.c * v + vi];
+            dl[v + vi] = xn[(long long)(g.c + 1) * v + vi];
+        }
+    } else
     for (int vi = t; vi < v; vi += 256) {
         const float lx = loc_n[2 * vi], ly = loc_n[2 * vi + 1];
         dance::Taps tp = dance::bilinear_taps(lx, ly, g.hf, g.wf, g.reflection);
@@ -993,6 +1002,21 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
     auto nohook = [](int) __attribute__((always_inline)) {};
     for (int c0 = 0; c0 < g.c; c0 += 64) {
         __syncthreads();
+        if constexpr (XIN) {
+            for (int s = vs; s < v; s += 16) {
+                h4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    _Float16 p, q;
+                    dance::split_half(xn[(long long)(c0 + 4 * lc + i) * v + s], p, q);
+                    hi[i] = p;
+                    lo[i] = q;
+                }
+                char *d = xs + ((lc >> 1) * G::VP + s) * 16 + 8 * (lc & 1);
+                *reinterpret_cast<h4 *>(d) = hi;
+                *reinterpret_cast<h4 *>(d + G::PLANE) = lo;
+            }
+        } else
 #pragma unroll 2
         for (int s = vs; s < v; s += 16) {
 #pragma clang fp contract(off)
@@ -1064,6 +1088,20 @@ __global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16
             dance::store_p16(yslot, v, (o0 >> 3) + gq, vv, h, val);
         }
     }
+}
+
+template <int RT, int TERMS>
+__global__ __launch_bounds__(256, 2) void k_gather_head16(Conv16Args a, Gather16Args g)
+{
+    gather_head16_body<RT, TERMS, false>(a, g);
+}
+
+// The same head block on a precomputed fp32 input (n, c + 2, v): Dsnake's init stage, whose
+// input is the fused [sampled | centre] features plus the de_location channels.
+template <int RT, int TERMS>
+__global__ __launch_bounds__(256, 2) void k_xin_head16(Conv16Args a, Gather16Args g)
+{
+    gather_head16_body<RT, TERMS, true>(a, g);
 }
 
 int pick_rt16(int v) { return v <= 64 ? 2 : (v <= 128 ? 4 : (v <= 224 ? 7 : 8)); }
@@ -1216,6 +1254,32 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     return launch_check(__func__);
 }
 
+extern "C" int dance_xin_head16(const float *x_in, int64_t x_stride, const void *w16, const float *bias_scaled,
+                                float w_inv_scale, const float *scale, const float *shift, void *y16,
+                                int64_t y_stride, int n, int v, int c, int mfma_terms, void *stream)
+{
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
+    DANCE_REQUIRE(c >= 64 && c % 64 == 0 && x_stride >= (int64_t)(c + 2) * v);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(x_in && w16 && bias_scaled && scale && shift && y16);
+    Conv16Args a;
+    a.x = nullptr; a.x_stride = 0; a.x_slot_stride = 0; a.w = (const h8 *)w16; a.bias_s = bias_scaled;
+    a.scale = scale; a.shift = shift; a.winv = w_inv_scale; a.y = (_Float16 *)y16; a.y_stride = y_stride;
+    a.y_slot_stride = 0; a.yf = nullptr; a.yf_stride = 0; a.v = v;
+    a.cin = (c + 2 + 31) & ~31; a.cout = 128; a.taps = 9;
+    a.dilation = 1; a.relu = 1; a.residual = 0; a.rowinit = nullptr; a.maxv = 0;
+    Gather16Args g;
+    g.feat = nullptr; g.att = nullptr; g.loc = x_in; g.image_idx = nullptr; g.att_out = nullptr; g.b = 1;
+    g.hf = 1; g.wf = 1; g.c = c; g.reflection = 0; g.deloc = DANCE_DELOC_DEMIN;
+    g.x_in = x_in; g.x_stride = x_stride;
+    const int rt = pick_rt16(v);
+    const size_t lds = (size_t)2 * 8 * (rt * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
+    LAUNCH_RT(k_xin_head16, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream, "dance_xin_head16", a, g);
+    return launch_check(__func__);
+}
+
 extern "C" int dance_gather_head16(const float *feat, const float *att, const float *loc,
                                    const int32_t *image_idx, const void *w16, const float *bias_scaled,
                                    float w_inv_scale, const float *scale, const float *shift, void *y16,
@@ -1241,6 +1305,7 @@ extern "C" int dance_gather_head16(const float *feat, const float *att, const fl
     g.feat = feat; g.att = att; g.loc = loc; g.image_idx = image_idx; g.att_out = att_out; g.b = b;
     g.hf = hf; g.wf = wf; g.c = c; g.reflection = padding_mode == DANCE_PAD_REFLECTION;
     g.deloc = deloc_type;
+    g.x_in = nullptr; g.x_stride = 0;
     const int rt = pick_rt16(v);
     const size_t lds = (size_t)2 * 8 * (rt * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
     LAUNCH_RT(k_gather_head16, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream,

@@ -651,7 +651,8 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
     DANCE_REQUIRE(c >= 64 && c % 64 == 0 && c + 2 <= 272);
     DANCE_REQUIRE(!individual_scale || whs != nullptr);
     DANCE_REQUIRE(!use_att || att != nullptr);
-    DANCE_REQUIRE(x_in != nullptr ? net32 != nullptr : feat != nullptr);
+    DANCE_REQUIRE(x_in != nullptr || feat != nullptr);
+    (void)net32;
     Workspace w = carve(workspace, n, v, 272);
     DANCE_REQUIRE(workspace_bytes >= w.bytes);
     _Float16 *state = reinterpret_cast<_Float16 *>(w.state);     // (n, 8 slots) P16
@@ -669,11 +670,11 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
     };
     DANCE_TRY(mark());
     if (x_in != nullptr) {
-        // precomputed fp32 input (Dsnake init): exact-fp32 head block writing P16
-        DANCE_TRY(dance_circconv(x_in, (long long)(c + 2) * v, net32->head_w, net32->head_b,
-                                 net32->head_scale, net32->head_shift, nullptr, nullptr,
-                                 reinterpret_cast<float *>(state), sstride, n, v, c + 2, 128, 9, 1,
-                                 DANCE_EP_RELU | DANCE_EP_AFFINE | DANCE_EP_OUT_P16, stream));
+        // precomputed fp32 input (Dsnake init): the head block of the fast mode, input split
+        // into hi/lo halves while it is staged
+        DANCE_TRY(dance_xin_head16(x_in, (long long)(c + 2) * v, net->head_w, net->head_bs, net->head_winv,
+                                   net->head_scale, net->head_shift, state, sstride, n, v, c, mfma_terms,
+                                   stream));
     } else {
         DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
                                       net->head_winv, net->head_scale, net->head_shift, state, sstride,

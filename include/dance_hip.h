@@ -313,6 +313,13 @@ int dance_gather_head16(const float *feat, const float *att, const float *loc,
                         int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf, int c,
                         int padding_mode, int deloc_type, int mfma_terms, void *stream);
 
+/* The same head block on a precomputed fp32 input x_in (n, c + 2, v), contour stride x_stride
+ * floats, instead of the gather: DsnakeHead.init's input, the fused [sampled | centre] features
+ * plus the two de_location channels (dsnake_head.py:718-741). */
+int dance_xin_head16(const float *x_in, int64_t x_stride, const void *w16, const float *bias_scaled,
+                     float w_inv_scale, const float *scale, const float *shift, void *y16,
+                     int64_t y_stride, int n, int v, int c, int mfma_terms, void *stream);
+
 typedef struct dance_snake_net16 {
     const void *head_w;  const float *head_bs, *head_scale, *head_shift;
     const void *res_w[7]; const float *res_bs[7], *res_scale[7], *res_shift[7];
@@ -334,8 +341,8 @@ int dance_res_stack16(const dance_snake_net16 *net_host, void *state, int64_t st
                       int n, int v, int mfma_terms, void *stream);
 
 /* dance_snake_evolve in the fast precision mode (same workspace size, same stage events;
- * the fusion / row-constant / prediction[0] stages are one kernel).  net32 is only needed
- * with x_in (fp32 precomputed head input). */
+ * the fusion / row-constant / prediction[0] stages are one kernel).  net32 is unused (kept for
+ * the signature; x_in now runs dance_xin_head16). */
 int dance_snake_evolve16(const dance_snake_net16 *net_host, const dance_snake_net *net32_host,
                          const float *feat, const float *att, const float *loc,
                          const int32_t *image_idx, const float *whs, const float *x_in, float *out,
