@@ -296,3 +296,39 @@ def test_res_stack_equals_seven_launches(device, v):
                                          s16.dilation[i], terms, st), "conv16")
         assert torch.equal(a, b), (v, terms)
         assert bool(torch.isfinite(a.float()).all()) and float(a[:, 7].float().abs().max()) > 0
+
+
+def test_deformation_replays_from_a_hip_graph(device):
+    """The C ABI promises that no entry point allocates, frees or synchronises
+    (include/dance_hip.h): a whole 3-iteration deformation captured into one HIP graph replays
+    to the bit-identical result, also after the inputs changed in place."""
+    cfg, sd, _ = dance_state_dict(1234, 128)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    feats = synthetic.make_smooth_features(2, 256, 50, 76, 21).to(device)
+    boxes = synthetic.make_boxes(24, 200, 304, 22, r_min=8, r_max=60)
+    loc = synthetic.make_circle_contours(boxes, 128).to(device)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).to(device)
+    idx = (torch.arange(24) % 2).float().to(device)
+    d = snake.ContourDeformer(nets)
+
+    def step():
+        return d.deform(feats, loc, idx, [(200, 304)] * 2, whs)[-1]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):                  # warm-up outside the capture (workspace, LDS attributes)
+            eager = step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    loc.add_(1.5)                           # same buffers, new contents
+    want = step().clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and not torch.equal(out, eager)
