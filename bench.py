@@ -369,8 +369,17 @@ def main():
         res7_ms = sum(events[k][it][1].elapsed_time(events[k][it][8])
                       for k in range(args.steps) for it in range(ITERS)) / launches
         stacked = args.precision != "fp32" and v <= 128 and os.environ.get("DANCE_RES_STACK", "1") != "0"
-        res_ms = res7_ms / 7.0                                  # per residual block
-        res_tflops = 2.0 * MACS_RES_BLOCK * v * n / (res_ms * 1e-3) / 1e12  # algorithmic
+        # DANCE_HEAD_STACK=1 (opt-in): gather + head block + the 7 residual blocks are ONE launch
+        # (k_head_stack16s); the events before the head and after the last residual block bracket it
+        head_stack = stacked and os.environ.get("DANCE_HEAD_STACK", "0") != "0"
+        if head_stack:
+            head_ms = head_ms + res7_ms                         # the fused launch
+            macs_dom = (CH + 2) * 128 * 9 + 7 * MACS_RES_BLOCK
+            res_ms = head_ms
+            res_tflops = 2.0 * macs_dom * v * n / (res_ms * 1e-3) / 1e12        # algorithmic
+        else:
+            res_ms = res7_ms / 7.0                              # per residual block
+            res_tflops = 2.0 * MACS_RES_BLOCK * v * n / (res_ms * 1e-3) / 1e12  # algorithmic
         gather_gbps = GATHER_BYTES_PER_VERTEX * v * n / (head_ms * 1e-3) / 1e9
         layout_ms = (sum(a.elapsed_time(b_) for a, b_ in layout_ev) / args.steps) if pre is None else 0.0
         ms_per_step = elapsed / args.steps * 1e3
@@ -380,7 +389,9 @@ def main():
             terms = 3 if args.precision == "fp16x3" else 1
             # every algorithmic product is three f16 MFMA products (A_lo*B_hi + A_hi*B_lo +
             # A_hi*B_hi); the roofline prices the EXECUTED f16 MFMA flops against the f16 peak
-            kname = ("k_res_stack16s<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
+            kname = ("k_head_stack16s<%d,%d> (gather + head SnakeBlock 258->128 + the 7 residual SnakeBlocks "
+                     "128->128, k=9, in one launch; %s f16 MFMA)" if head_stack else
+                     "k_res_stack16s<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
                      "%s f16 MFMA 16x16x32)" if stacked else
                      "k_conv16%s<%d,%d> (residual SnakeBlock 128->128, k=9, %s f16 MFMA; 7 launches "
                      "between the two events, figures per launch)")
@@ -389,17 +400,20 @@ def main():
             roof = {"kernel": kname,
                     "bound": "mfma", "achieved": terms * res_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": terms * res_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                    "avg_launch_ms": res7_ms if stacked else res_ms,
-                    "algorithmic_GFLOP_per_launch": 2.0 * MACS_RES_BLOCK * v * n * (7 if stacked else 1) / 1e9,
+                    "avg_launch_ms": res_ms if head_stack else res7_ms if stacked else res_ms,
+                    "algorithmic_GFLOP_per_launch": (2.0 * macs_dom * v * n / 1e9 if head_stack else
+                                                     2.0 * MACS_RES_BLOCK * v * n * (7 if stacked else 1) / 1e9),
                     "algorithmic_TFLOPs": res_tflops, "mfma_per_product": terms,
                     "note": "achieved = executed f16 MFMA flops (%d x algorithmic) / spacing of the two HIP events "
                             "around the residual blocks in the timed steps (event spacing includes the "
                             "inter-kernel gap, ~10 us per launch)" % terms}
             if terms == 3:
                 roof["traffic"], roof["traffic_source"] = measured_traffic(
-                    "k_res_stack16s" if stacked else "k_conv16s" if rt <= 4 else "k_conv16<", n)
+                    "k_head_stack16s" if head_stack else "k_res_stack16s" if stacked else
+                    "k_conv16s" if rt <= 4 else "k_conv16<", n)
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"
-            gkernel = "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt
+            gkernel = ("k_head_stack16s<%d> (fused gather + head SnakeBlock + residual stack)" % rt if head_stack
+                       else "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt)
         else:
             roof = {"kernel": "k_circconv<%d> (residual SnakeBlock 128->128, k=9, f32 MFMA)" % rt,
                     "bound": "mfma", "achieved": res_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
@@ -428,8 +442,9 @@ def main():
             "gather": {"kernel": gkernel,
                        "algorithmic_GBps": gather_gbps, "frac_of_hbm_peak": gather_gbps / PEAK_HBM_GBPS,
                        "avg_launch_ms": head_ms,
-                       "note": "the fused kernel is MFMA-bound (85 MFLOP per 526 KB gathered per "
-                               "contour-iteration), not HBM-bound",
+                       "note": "the fused kernel is MFMA-bound (%d MFLOP per 526 KB gathered per "
+                               "contour-iteration), not HBM-bound" % (
+                                   2.0 * ((CH + 2) * 128 * 9 + (7 * MACS_RES_BLOCK if head_stack else 0)) * v / 1e6),
                        "standalone_kernel": "k_gather (gather + de_location + concat only, untimed extra)",
                        "standalone_ms": gather_alone_ms,
                        "standalone_algorithmic_GBps": GATHER_BYTES_PER_VERTEX * v * n / (gather_alone_ms * 1e-3) / 1e9,

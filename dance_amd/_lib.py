@@ -95,6 +95,8 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_xin_head16": (c_int, [P, c_int64, P, P, c_float, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int, P]),
+    "dance_head_stack16": (c_int, [POINTER(SnakeNet16Struct), P, P, P, P, P, c_int64, c_int64, P, c_int, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_snake_evolve16": (c_int, [POINTER(SnakeNet16Struct), POINTER(SnakeNetStruct), P, P, P, P, P,
                                      P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_float, c_int, POINTER(c_void_p), P]),

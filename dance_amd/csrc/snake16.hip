@@ -624,14 +624,14 @@ struct Stack16Args {
     int v, nlayers;
 };
 
+// The layers of the stack for one contour whose 128-channel input image already sits in LDS
+// (xs: chunk images 0 | 1) behind a barrier.
 template <int RT, int TERMS>
-__global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
+__device__ __forceinline__ void res_stack16_layers(const Stack16Args &a, long long nn, char *xs)
 {
     static_assert(RT <= 4, "rings of at most 128 vertices");
-    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NW = 4, NB = 4, CT = 2 * RT;
+    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NB = 4, CT = 2 * RT;
     using G = Geo<RT, CBC>;
-    using S = StageGeo<RT, CBC, NW>;
-    extern __shared__ __attribute__((aligned(16))) char xs[];   // chunk images 0 | 1 = 128 channels
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c16 = lane & 15, q4 = lane >> 4;
@@ -640,9 +640,80 @@ __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
     const long long wbs_b = 128 * 16, wts_b = 16 * wbs_b, wps_b = 9 * wts_b;
     const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
     auto nohook = [](int) __attribute__((always_inline)) {};
+    _Float16 *sn = a.state + nn * a.stride;
+    for (int l = 0; l < a.nlayers; ++l) {
+        f32x4 acc[2][CT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s[l] + o0 + 16 * i + 4 * q4);
+            const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+                acc[i][j] = bv;
+        }
+        const char *wl = reinterpret_cast<const char *>(a.w[l]) + (long long)o0 * 16;
+        const int dil = a.dilation[l];
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c)
+            mfma16_core_s<RT, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b, wlane,
+                                                  wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, nohook);
+        __syncthreads();                    // every wave has read the whole image
+        // epilogue: lane = vertex 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3; indices
+        // made opaque so the compiler does not hoist the address math over the MFMAs
+        int ce = c16, qe = q4;
+        asm volatile("" : "+v"(ce), "+v"(qe));
+        _Float16 *yslot = sn + (l + 1) * a.slot;
+        const float winv = a.winv[l];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int ob = o0 + 16 * i2 + 4 * qe;
+            const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale[l] + ob);
+            const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift[l] + ob);
+            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
+            const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const int vv = j * 16 + ce;
+                if (vv >= v)
+                    continue;
+                char *q = xs + xchunk * G::BYTES + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
+                const h4 rh = *reinterpret_cast<const h4 *>(q);
+                const h4 rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
+                h4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
+                    x += (float)rh[i] + (float)rl[i];
+                    _Float16 xh, xl;
+                    dance::split_half(x, xh, xl);
+                    hi[i] = xh;
+                    lo[i] = xl;
+                }
+                // next block's input, in place (this lane owns these two half-words)
+                *reinterpret_cast<h4 *>(q) = hi;
+                *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
+                _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
+                *reinterpret_cast<h4 *>(d) = hi;
+                *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
+            }
+        }
+        __syncthreads();                    // image = block l + 1's input
+    }
+}
 
+template <int RT, int TERMS>
+__global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
+{
+    constexpr int CBC = 8, NW = 4;
+    using G = Geo<RT, CBC>;
+    using S = StageGeo<RT, CBC, NW>;
+    extern __shared__ __attribute__((aligned(16))) char xs[];   // chunk images 0 | 1 = 128 channels
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int v = a.v;
     for (long long nn = blockIdx.x; nn < n; nn += gridDim.x) {
-        _Float16 *sn = a.state + nn * a.stride;
+        const _Float16 *sn = a.state + nn * a.stride;
         {
             u32x4 sreg[S::N];
 #pragma unroll
@@ -653,65 +724,7 @@ __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
             }
         }
         __syncthreads();
-        for (int l = 0; l < a.nlayers; ++l) {
-            f32x4 acc[2][CT];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s[l] + o0 + 16 * i + 4 * q4);
-                const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                for (int j = 0; j < CT; ++j)
-                    acc[i][j] = bv;
-            }
-            const char *wl = reinterpret_cast<const char *>(a.w[l]) + (long long)o0 * 16;
-            const int dil = a.dilation[l];
-#pragma unroll 1
-            for (int c = 0; c < 2; ++c)
-                mfma16_core_s<RT, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b, wlane,
-                                                      wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, nohook);
-            __syncthreads();                    // every wave has read the whole image
-            // epilogue: lane = vertex 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3; indices
-            // made opaque so the compiler does not hoist the address math over the MFMAs
-            int ce = c16, qe = q4;
-            asm volatile("" : "+v"(ce), "+v"(qe));
-            _Float16 *yslot = sn + (l + 1) * a.slot;
-            const float winv = a.winv[l];
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
-                const int ob = o0 + 16 * i2 + 4 * qe;
-                const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale[l] + ob);
-                const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift[l] + ob);
-                const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-                const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
-                const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
-#pragma unroll
-                for (int j = 0; j < CT; ++j) {
-                    const int vv = j * 16 + ce;
-                    if (vv >= v)
-                        continue;
-                    char *q = xs + xchunk * G::BYTES + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
-                    const h4 rh = *reinterpret_cast<const h4 *>(q);
-                    const h4 rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
-                    h4 hi, lo;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float x = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
-                        x += (float)rh[i] + (float)rl[i];
-                        _Float16 xh, xl;
-                        dance::split_half(x, xh, xl);
-                        hi[i] = xh;
-                        lo[i] = xl;
-                    }
-                    // next block's input, in place (this lane owns these two half-words)
-                    *reinterpret_cast<h4 *>(q) = hi;
-                    *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
-                    _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
-                    *reinterpret_cast<h4 *>(d) = hi;
-                    *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
-                }
-            }
-            __syncthreads();                    // image = block l + 1's input
-        }
+        res_stack16_layers<RT, TERMS>(a, nn, xs);
     }
 }
 
@@ -932,7 +945,9 @@ struct Gather16Args {
     long long x_stride;         // the gather (Dsnake init: fused features + de_location channels)
 };
 
-template <int RT, int TERMS, bool XIN>
+// TO_LDS: the workgroup goes on with the residual stack (k_head_stack16s): two chunk images are
+// reserved, and the epilogue writes the block's output into them as well as to its HBM slot.
+template <int RT, int TERMS, bool XIN, bool TO_LDS = false>
 __device__ __forceinline__ void gather_head16_body(const Conv16Args &a, const Gather16Args &g)
 {
     constexpr int CBC = 8;                                      // 64 channels per chunk
@@ -941,7 +956,7 @@ __device__ __forceinline__ void gather_head16_body(const Conv16Args &a, const Ga
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int v = a.v;
     char *xs = smem;                                            // one chunk image
-    float *tw = reinterpret_cast<float *>(smem + G::BYTES);     // [v][4]
+    float *tw = reinterpret_cast<float *>(smem + (TO_LDS ? 2 : 1) * G::BYTES);     // [v][4]
     int *toff = reinterpret_cast<int *>(tw + 4 * v);            // [v][4]
     float *dl = reinterpret_cast<float *>(toff + 4 * v);        // [2][v]
     float *red = dl + 2 * v;                                    // [16]
@@ -1071,6 +1086,8 @@ __device__ __forceinline__ void gather_head16_body(const Conv16Args &a, const Ga
                                  wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
     }
     _Float16 *yslot = a.y + nn * a.y_stride;
+    if constexpr (TO_LDS)
+        __syncthreads();                        // every wave is done reading the gather buffer
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale + o0 + 8 * gq + 4 * h);
@@ -1086,8 +1103,25 @@ __device__ __forceinline__ void gather_head16_body(const Conv16Args &a, const Ga
             for (int i = 0; i < 4; ++i)
                 val[i] = relu_nan(acc[0][rt][4 * gq + i] * a.winv) * sc[i] + sh[i];
             dance::store_p16(yslot, v, (o0 >> 3) + gq, vv, h, val);
+            if constexpr (TO_LDS) {
+                // the same words into the LDS image (row = channel block, chunks of 8 blocks)
+                const int row = (o0 >> 3) + gq;
+                h4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    _Float16 p, q;
+                    dance::split_half(val[i], p, q);
+                    hi[i] = p;
+                    lo[i] = q;
+                }
+                char *d = xs + (row >> 3) * G::BYTES + ((row & 7) * G::VP + vv) * 16 + 8 * h;
+                *reinterpret_cast<h4 *>(d) = hi;
+                *reinterpret_cast<h4 *>(d + G::PLANE) = lo;
+            }
         }
     }
+    if constexpr (TO_LDS)
+        __syncthreads();                        // the image is complete
 }
 
 template <int RT, int TERMS>
@@ -1102,6 +1136,18 @@ template <int RT, int TERMS>
 __global__ __launch_bounds__(256, 2) void k_xin_head16(Conv16Args a, Gather16Args g)
 {
     gather_head16_body<RT, TERMS, true>(a, g);
+}
+
+// Fused gather + head block + the 7 residual blocks (V <= 128): the head's output goes to its
+// state slot in HBM and straight into the LDS image the residual stack works on -- no second
+// launch, no re-read of slot 0, and one workgroup's gather phases (HBM latency) overlap the
+// other resident workgroup's residual-block MFMAs.
+template <int RT, int TERMS>
+__global__ __launch_bounds__(256, 2) void k_head_stack16s(Conv16Args a, Gather16Args g, Stack16Args st)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_hs[];
+    gather_head16_body<RT, TERMS, false, true>(a, g);
+    res_stack16_layers<RT, TERMS>(st, blockIdx.x, smem_hs);
 }
 
 int pick_rt16(int v) { return v <= 64 ? 2 : (v <= 128 ? 4 : (v <= 224 ? 7 : 8)); }
@@ -1228,6 +1274,46 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
     const int rt = pick_rt16(v);
     const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // the whole 128-channel image
     LAUNCH_RT24(k_res_stack16s, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_head_stack16(const dance_snake_net16 *net, const float *feat, const float *att,
+                                  const float *loc, const int32_t *image_idx, void *state, int64_t stride,
+                                  int64_t slot, float *att_out, int n, int v, int b, int hf, int wf,
+                                  int padding_mode, int deloc_type, int mfma_terms, void *stream)
+{
+    DANCE_REQUIRE(net != nullptr && n >= 0 && v >= 16 && v <= 128);
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    const int c = net->feat_channels;
+    DANCE_REQUIRE(b >= 1 && hf >= 1 && wf >= 1 && (long long)hf * wf < (1ll << 30));
+    DANCE_REQUIRE(c >= 64 && c % 64 == 0);
+    DANCE_REQUIRE(padding_mode == DANCE_PAD_ZEROS || padding_mode == DANCE_PAD_REFLECTION);
+    DANCE_REQUIRE(deloc_type >= DANCE_DELOC_DERANGE && deloc_type <= DANCE_DELOC_NONE);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(feat && loc && state && net->head_w && net->head_bs && net->head_scale && net->head_shift);
+    Conv16Args a;
+    a.x = nullptr; a.x_stride = 0; a.x_slot_stride = 0; a.w = (const h8 *)net->head_w; a.bias_s = net->head_bs;
+    a.scale = net->head_scale; a.shift = net->head_shift; a.winv = net->head_winv; a.y = (_Float16 *)state;
+    a.y_stride = stride; a.y_slot_stride = 0; a.yf = nullptr; a.yf_stride = 0; a.v = v;
+    a.cin = (c + (deloc_type != DANCE_DELOC_NONE ? 2 : 0) + 31) & ~31; a.cout = 128; a.taps = 9;
+    a.dilation = 1; a.relu = 1; a.residual = 0; a.rowinit = nullptr; a.maxv = 0;
+    Gather16Args g;
+    g.feat = feat; g.att = att; g.loc = loc; g.image_idx = image_idx; g.att_out = att_out; g.b = b;
+    g.hf = hf; g.wf = wf; g.c = c; g.reflection = padding_mode == DANCE_PAD_REFLECTION;
+    g.deloc = deloc_type; g.x_in = nullptr; g.x_stride = 0;
+    Stack16Args st;
+    st.state = (_Float16 *)state; st.stride = stride; st.slot = slot; st.v = v; st.nlayers = 7;
+    for (int i = 0; i < 7; ++i) {
+        DANCE_REQUIRE(net->res_w[i] && net->res_bs[i] && net->res_scale[i] && net->res_shift[i]);
+        DANCE_REQUIRE(net->dilation[i] >= 1 && net->dilation[i] * 4 <= 16);
+        st.w[i] = (const h8 *)net->res_w[i]; st.bias_s[i] = net->res_bs[i]; st.scale[i] = net->res_scale[i];
+        st.shift[i] = net->res_shift[i]; st.winv[i] = net->res_winv[i]; st.dilation[i] = net->dilation[i];
+    }
+    const int rt = pick_rt16(v);
+    const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
+    LAUNCH_RT24(k_head_stack16s, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream,
+                "dance_head_stack16", a, g, st);
     return launch_check(__func__);
 }
 

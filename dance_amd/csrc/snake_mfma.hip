@@ -675,15 +675,27 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
         DANCE_TRY(dance_xin_head16(x_in, (long long)(c + 2) * v, net->head_w, net->head_bs, net->head_winv,
                                    net->head_scale, net->head_shift, state, sstride, n, v, c, mfma_terms,
                                    stream));
-    } else {
+    }
+    static const int use_stack = getenv("DANCE_RES_STACK") ? atoi(getenv("DANCE_RES_STACK")) : 1;
+    // opt-in (DANCE_HEAD_STACK=1): measured no faster than the two launches (experiments)
+    static const int use_head_stack = getenv("DANCE_HEAD_STACK") ? atoi(getenv("DANCE_HEAD_STACK")) : 0;
+    const bool head_stack = x_in == nullptr && use_stack && use_head_stack && v <= 128;
+    if (head_stack) {
+        // gather + head block + the 7 residual blocks in one launch; its time is booked on stage head
+        DANCE_TRY(dance_head_stack16(net, feat, att, loc, image_idx, state, sstride, slot,
+                                     use_att ? w.att_s : nullptr, n, v, b, hf, wf, padding_mode, deloc_type,
+                                     mfma_terms, stream));
+    } else if (x_in == nullptr) {
         DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
                                       net->head_winv, net->head_scale, net->head_shift, state, sstride,
                                       use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
                                       deloc_type, mfma_terms, stream));
     }
     DANCE_TRY(mark());
-    static const int use_stack = getenv("DANCE_RES_STACK") ? atoi(getenv("DANCE_RES_STACK")) : 1;
-    if (use_stack && v <= 128) {
+    if (head_stack) {
+        for (int i = 0; i < 7; ++i)
+            DANCE_TRY(mark());
+    } else if (use_stack && v <= 128) {
         // one launch for the 7 residual blocks; its time is booked on stage res0
         DANCE_TRY(dance_res_stack16(net, state, sstride, slot, n, v, mfma_terms, stream));
         for (int i = 0; i < 7; ++i)

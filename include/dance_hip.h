@@ -340,6 +340,15 @@ typedef struct dance_snake_net16 {
 int dance_res_stack16(const dance_snake_net16 *net_host, void *state, int64_t stride, int64_t slot,
                       int n, int v, int mfma_terms, void *stream);
 
+/* dance_gather_head16 followed by dance_res_stack16 in ONE launch (v <= 128): the head block's
+ * output goes to slot 0 of `state` and straight into the LDS image the residual blocks work on.
+ * Bit-identical to the two separate calls.  reference: evolve snake_head.py:1639-1652 +
+ * _SnakeNet.forward :262-268. */
+int dance_head_stack16(const dance_snake_net16 *net_host, const float *feat, const float *att,
+                       const float *loc, const int32_t *image_idx, void *state, int64_t stride,
+                       int64_t slot, float *att_out, int n, int v, int b, int hf, int wf,
+                       int padding_mode, int deloc_type, int mfma_terms, void *stream);
+
 /* dance_snake_evolve in the fast precision mode (same workspace size, same stage events;
  * the fusion / row-constant / prediction[0] stages are one kernel).  net32 is unused (kept for
  * the signature; x_in now runs dance_xin_head16). */

@@ -332,3 +332,40 @@ def test_deformation_replays_from_a_hip_graph(device):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want) and not torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("v", [16, 40, 100, 128])
+def test_head_stack_equals_separate_launches(device, v):
+    """dance_head_stack16 (gather + head block + 7 residual blocks in one launch, the head's
+    output handed over in LDS) is bit-identical to dance_gather_head16 + dance_res_stack16."""
+    import ctypes
+    from dance_amd._lib import check, current_stream, lib, ptr
+    cfg, sd, _ = dance_state_dict(77, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer2."), device)
+    s16 = net.struct16
+    b, hf, wf, n = 2, 40, 56, 29
+    feats = synthetic.make_features(b, 256, hf, wf, 5).to(device)
+    nhwc, att = ops.nchw_to_nhwc(feats, 1)
+    boxes = synthetic.make_boxes(n, hf * 4, wf * 4, v, r_min=6, r_max=50)
+    loc = synthetic.make_circle_contours(boxes, v).to(device)
+    loc[3] += 400.0                                             # leaves the image: reflection padding
+    idx = (torch.arange(n) % b).to(torch.int32).to(device)
+    slot = 256 * v
+    for terms in (3, 1):
+        a = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
+        bb = a.clone()
+        att_a = torch.zeros((n, v), device=device)
+        att_b = torch.zeros((n, v), device=device)
+        with torch.cuda.device(device):
+            st = current_stream()
+            check(lib().dance_head_stack16(ctypes.byref(s16), ptr(nhwc), ptr(att), ptr(loc), ptr(idx), ptr(a),
+                                           a.stride(0), slot, ptr(att_a), n, v, b, hf, wf, ops.PAD_REFLECTION,
+                                           ops.DELOC["derange"], terms, st), "head_stack16")
+            check(lib().dance_gather_head16(ptr(nhwc), ptr(att), ptr(loc), ptr(idx), s16.head_w, s16.head_bs,
+                                            s16.head_winv, s16.head_scale, s16.head_shift, ptr(bb), bb.stride(0),
+                                            ptr(att_b), n, v, b, hf, wf, 256, ops.PAD_REFLECTION,
+                                            ops.DELOC["derange"], terms, st), "gather_head16")
+            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(bb), bb.stride(0), slot, n, v, terms, st), "stack")
+        assert torch.equal(a, bb), (v, terms)
+        assert torch.equal(att_a, att_b)
+        assert bool(torch.isfinite(a.float()).all()) and float(a[:, 7].float().abs().max()) > 0
