@@ -31,6 +31,7 @@ constexpr int RT_THREADS = 256;
 constexpr int RT_MAX_V = 512;
 constexpr int RT_BM_WORDS = 10240;                 // 40 KB of LDS: three workgroups per CU
 constexpr long long RT_BM_BITS = RT_BM_WORDS * 32ll;
+constexpr double RT_CLAMP = 1048576.0;             // 5x grid: +-209,715 px; 512 edges x 2^21 steps < 2^31
 
 __device__ __forceinline__ int wave_incl_add(int x, int lane)
 {
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(RT_THREADS) void k_polygon_rle(const float *__restr
     int umin = INT_MAX, umax = INT_MIN;
     for (int j = tid; j < v; j += RT_THREADS) {
         const float2 p = reinterpret_cast<const float2 *>(polys)[(long long)n * v + j];
-        const int x = (int)(5.0 * (double)p.x + .5), y = (int)(5.0 * (double)p.y + .5);
+        // the library's (int)(5 * c + .5); magnitudes no image reaches (and NaN / inf, where the
+        // library's conversion is undefined) are clamped so that the step count stays in int range
+        const int x = (int)fmin(fmax(5.0 * (double)p.x + .5, -RT_CLAMP), RT_CLAMP);
+        const int y = (int)fmin(fmax(5.0 * (double)p.y + .5, -RT_CLAMP), RT_CLAMP);
         vx[j] = x;
         vy[j] = y;
         if (j == 0) {

@@ -122,7 +122,8 @@ int dance_attender(const float *x, const float *w1, const float *gn1_w, const fl
  *   counts (n,cap) u32: run lengths in column-major order, first run = zeros; m (n) i32 = number
  *   of runs (rows with m > cap hold the first cap runs); area (n) u32 = sum of the runs of ones
  *   (rleArea), may be NULL; status (n) i32, may be NULL: 0 ok, 1 = m > cap, 2 = size not
- *   supported.  Non-finite coordinates convert to 0 (the library's conversion is undefined). */
+ *   supported.  Coordinates beyond +-209,715 px and non-finite ones (the library's conversion of
+ *   those is undefined) are clamped to that range. */
 int dance_polygon_rle(const float *polys, const int32_t *sizes, int n, int v, int h, int w,
                       uint32_t *counts, int cap, int32_t *m, uint32_t *area, int32_t *status,
                       void *stream);

@@ -151,6 +151,21 @@ def test_get_polygon_rles_matches_the_reference_call_shape(device):
     assert rle.get_polygon_rles(contours[:0].flatten(1), (h, w)) == []
 
 
+def test_wild_coordinates_terminate(device):
+    """NaN / inf / absurd coordinates (a collapsed contour is NaN in the reference's `derange`)
+    are clamped: the kernel finishes and still returns a valid run list."""
+    h, w = 60, 80
+    polys = torch.tensor([[[10.0, 10.0], [float("nan"), 20.0], [30.0, float("inf")], [5.0, 40.0]],
+                          [[-1e30, 5.0], [1e30, 5.0], [1e30, 50.0], [-1e30, 50.0]],
+                          [[float("nan")] * 2] * 4], dtype=torch.float32)
+    out = rle.polygon_rle(polys.to(device), (h, w))
+    counts, m = out.counts.cpu().numpy().view(np.uint32), out.m.cpu().numpy()
+    for i in range(3):
+        assert m[i] >= 1 and int(counts[i, :m[i]].sum()) == h * w
+    # rows 5..49 of every column: the second polygon spans the whole width
+    assert int(out.area[1]) == 45 * w
+
+
 def test_errors(device):
     with pytest.raises(RuntimeError, match="GPU"):
         rle.polygon_rle(torch.zeros((1, 4, 2)), (10, 10))
