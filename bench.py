@@ -368,10 +368,11 @@ def main():
                       for k in range(args.steps) for it in range(ITERS)) / launches
         res7_ms = sum(events[k][it][1].elapsed_time(events[k][it][8])
                       for k in range(args.steps) for it in range(ITERS)) / launches
-        stacked = args.precision != "fp32" and v <= 128 and os.environ.get("DANCE_RES_STACK", "1") != "0"
+        stacked = args.precision != "fp32" and os.environ.get("DANCE_RES_STACK", "1") != "0" and \
+            (v <= 128 or os.environ.get("DANCE_RES_STACK_WIDE", "1") != "0")
         # DANCE_HEAD_STACK=1 (opt-in): gather + head block + the 7 residual blocks are ONE launch
         # (k_head_stack16s); the events before the head and after the last residual block bracket it
-        head_stack = stacked and os.environ.get("DANCE_HEAD_STACK", "0") != "0"
+        head_stack = stacked and v <= 128 and os.environ.get("DANCE_HEAD_STACK", "0") != "0"
         if head_stack:
             head_ms = head_ms + res7_ms                         # the fused launch
             macs_dom = (CH + 2) * 128 * 9 + 7 * MACS_RES_BLOCK
@@ -391,7 +392,8 @@ def main():
             # A_hi*B_hi); the roofline prices the EXECUTED f16 MFMA flops against the f16 peak
             kname = ("k_head_stack16s<%d,%d> (gather + head SnakeBlock 258->128 + the 7 residual SnakeBlocks "
                      "128->128, k=9, in one launch; %s f16 MFMA)" if head_stack else
-                     "k_res_stack16s<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
+                     ("k_res_stack16s" if v <= 128 else "k_res_stack16w") +
+                     "<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
                      "%s f16 MFMA 16x16x32)" if stacked else
                      "k_conv16%s<%d,%d> (residual SnakeBlock 128->128, k=9, %s f16 MFMA; 7 launches "
                      "between the two events, figures per launch)")
@@ -409,7 +411,8 @@ def main():
                             "inter-kernel gap, ~10 us per launch)" % terms}
             if terms == 3:
                 roof["traffic"], roof["traffic_source"] = measured_traffic(
-                    "k_head_stack16s" if head_stack else "k_res_stack16s" if stacked else
+                    "k_head_stack16s" if head_stack else ("k_res_stack16s" if v <= 128 else "k_res_stack16w")
+                    if stacked else
                     "k_conv16s" if rt <= 4 else "k_conv16<", n)
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"
             gkernel = ("k_head_stack16s<%d> (fused gather + head SnakeBlock + residual stack)" % rt if head_stack

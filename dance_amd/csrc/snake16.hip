@@ -241,6 +241,82 @@ __device__ __forceinline__ void mfma16_core_s(f32x4 (&acc)[2][2 * RT], const cha
 #undef DANCE_LOAD_B
 }
 
+// mfma16_core_s for rings above 128 vertices, where a wave owns only CTW of the ring's 16-wide
+// vertex tiles, starting at tile j0 (the vertex tiles are split over two groups of waves).
+// RTG sizes the LDS image (row stride 32 * RTG + 1 words).
+template <int RTG, int CTW, int NST, int AD, int NB, int TERMS>
+__device__ __forceinline__ void mfma16_core_sw(f32x4 (&acc)[2][CTW], const char *xs, unsigned lds0, int v,
+                                               const char *wchunk, unsigned wlane, long long wps_b,
+                                               long long wts_b, long long wstep_b, int taps, int dilation,
+                                               int c16, int q4, int j0)
+{
+    constexpr int CT = CTW, NT = NST * CT, DB = NB - 1, D = AD - 1;
+    static_assert(NST % AD == 0 && D <= NST && D >= 1, "weight buffer rotation must close over a tap");
+    static_assert(NT % NB == 0 && DB <= NT - CT && DB >= 1, "tile buffer rotation must close over a tap");
+    using G = Geo<RTG, 4 * NST>;
+    constexpr int SSTEP = 4 * G::VP * 16;
+    const unsigned rowb = lds0 + q4 * G::VP * 16;
+    const unsigned lim = rowb + v * 16, d16 = dilation * 16, v16 = v * 16;
+    unsigned p[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+        p[j] = rowb + ring16((j0 + j) * 16 + c16, -(taps >> 1) * dilation, v) * 16;
+
+    h8 ah[AD][2], al[AD][2];
+#define DANCE_LOAD_A(SLOT, PTR)                                                                   \
+    do {                                                                                          \
+        const char *pa_ = (PTR);                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                        \
+            ah[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wlane + i_ * 256);                 \
+            if constexpr (TERMS == 3)                                                             \
+                al[SLOT][i_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + i_ * 256);     \
+        }                                                                                         \
+    } while (0)
+#define DANCE_LOAD_B(Q)                                                                           \
+    do {                                                                                          \
+        constexpr int q_ = (Q) % NT, s_ = q_ / CT, j_ = q_ % CT;                                  \
+        bh[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[j_] + s_ * SSTEP);                    \
+        if constexpr (TERMS == 3)                                                                 \
+            bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[j_] + s_ * SSTEP + G::PLANE);     \
+        if (s_ == NST - 1) {                                                                      \
+            const unsigned tpos_ = p[j_] + d16;                                                   \
+            p[j_] = tpos_ >= lim ? tpos_ - v16 : tpos_;                                           \
+        }                                                                                         \
+    } while (0)
+#pragma unroll
+    for (int q = 0; q < D; ++q)
+        DANCE_LOAD_A(q, wchunk + q * wstep_b);
+    h8 bh[NB], bl[NB];
+    dance::static_for<0, DB>([&](auto q) __attribute__((always_inline)) { DANCE_LOAD_B(decltype(q)::value); });
+
+    const char *wtap = wchunk;
+    for (int tap = 0; tap < taps; ++tap) {
+        const bool more = tap + 1 < taps;
+        dance::static_for<0, NT>([&](auto qq) __attribute__((always_inline)) {
+            constexpr int q = decltype(qq)::value, s = q / CT, j = q % CT;
+            if constexpr (j == 0) {
+                if (s + D < NST)
+                    DANCE_LOAD_A((s + D) % AD, wtap + (s + D) * wstep_b);
+                else if (more)
+                    DANCE_LOAD_A((s + D) % AD, wtap + wts_b + (s + D - NST) * wstep_b);
+            }
+            DANCE_LOAD_B(q + DB);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TERMS == 3) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][0], bh[q % NB], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AD][1], bh[q % NB], acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][0], bl[q % NB], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][1], bl[q % NB], acc[1][j], 0, 0, 0);
+            }
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][0], bh[q % NB], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AD][1], bh[q % NB], acc[1][j], 0, 0, 0);
+        });
+        wtap += wts_b;
+    }
+#undef DANCE_LOAD_A
+#undef DANCE_LOAD_B
+}
+
 // Staging of the next chunk image: this wave's rows (wave, wave + NW, ...), lanes along the
 // row; lanes past the ring length repeat the last vertex (same value to the same address),
 // which keeps loads and stores branch-free and the staging array in registers.
@@ -725,6 +801,96 @@ __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
         }
         __syncthreads();
         res_stack16_layers<RT, TERMS>(a, nn, xs);
+    }
+}
+
+// The residual stack for rings of 129..256 vertices: 8 waves = 4 output-channel tiles x 2 halves
+// of the ring's 16-wide vertex tiles, the 128-channel image (115 / 132 KB) resident in LDS, one
+// workgroup per CU.  Same arithmetic per output element as k_conv16 / k_conv16s.
+template <int RT, int TERMS>
+__global__ __launch_bounds__(512) void k_res_stack16w(Stack16Args a, int n)
+{
+    static_assert(RT == 7 || RT == 8, "rings of 129..256 vertices");
+    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NW = 8, CTW = RT, NB = (NST * CTW) % 4 == 0 ? 4 : 2;
+    using G = Geo<RT, CBC>;
+    using S = StageGeo<RT, CBC, NW>;
+    extern __shared__ __attribute__((aligned(16))) char xs[];   // chunk images 0 | 1 = 128 channels
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int o0 = (wave & 3) * 32, j0 = (wave >> 2) * CTW;
+    const int v = a.v;
+    const long long wbs_b = 128 * 16, wts_b = 16 * wbs_b, wps_b = 9 * wts_b;
+    const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
+
+    for (long long nn = blockIdx.x; nn < n; nn += gridDim.x) {
+        _Float16 *sn = a.state + nn * a.stride;
+        {
+            u32x4 sreg[S::N];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                stage_load<RT, CBC, NW>(sreg, 0, S::N, reinterpret_cast<const char *>(sn) + (long long)c * CBC * v * 16,
+                                        v, wave, lane);
+                stage_commit<RT, CBC, NW>(sreg, xs, c * G::BYTES, v, wave, lane);
+            }
+        }
+        __syncthreads();
+        for (int l = 0; l < a.nlayers; ++l) {
+            f32x4 acc[2][CTW];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s[l] + o0 + 16 * i + 4 * q4);
+                const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < CTW; ++j)
+                    acc[i][j] = bv;
+            }
+            const char *wl = reinterpret_cast<const char *>(a.w[l]) + (long long)o0 * 16;
+            const int dil = a.dilation[l];
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c)
+                mfma16_core_sw<RT, CTW, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b,
+                                                            wlane, wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, j0);
+            __syncthreads();                    // every wave has read the whole image
+            int ce = c16, qe = q4;
+            asm volatile("" : "+v"(ce), "+v"(qe));
+            _Float16 *yslot = sn + (l + 1) * a.slot;
+            const float winv = a.winv[l];
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int ob = o0 + 16 * i2 + 4 * qe;
+                const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale[l] + ob);
+                const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift[l] + ob);
+                const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+                const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
+                const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
+#pragma unroll
+                for (int j = 0; j < CTW; ++j) {
+                    const int vv = (j0 + j) * 16 + ce;
+                    if (vv >= v)
+                        continue;
+                    char *q = xs + xchunk * G::BYTES + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
+                    const h4 rh = *reinterpret_cast<const h4 *>(q);
+                    const h4 rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
+                    h4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float x = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
+                        x += (float)rh[i] + (float)rl[i];
+                        _Float16 xh, xl;
+                        dance::split_half(x, xh, xl);
+                        hi[i] = xh;
+                        lo[i] = xl;
+                    }
+                    *reinterpret_cast<h4 *>(q) = hi;
+                    *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
+                    _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
+                    *reinterpret_cast<h4 *>(d) = hi;
+                    *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
+                }
+            }
+            __syncthreads();                    // image = block l + 1's input
+        }
     }
 }
 
@@ -1258,7 +1424,7 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
 extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int64_t stride, int64_t slot,
                                  int n, int v, int mfma_terms, void *stream)
 {
-    DANCE_REQUIRE(net != nullptr && n >= 0 && v >= 16 && v <= 128);
+    DANCE_REQUIRE(net != nullptr && n >= 0 && v >= 16 && v <= 256);
     DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     if (n == 0)
         return 0;
@@ -1273,6 +1439,16 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
     }
     const int rt = pick_rt16(v);
     const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // the whole 128-channel image
+    if (rt > 4) {                                                  // 129..256 vertices: 8 waves, one workgroup per CU
+        int rc_ = 0;
+        if (rt == 7)
+            LAUNCH_ONE(k_res_stack16w, 7, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else
+            LAUNCH_ONE(k_res_stack16w, 8, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        if (rc_)
+            return rc_;
+        return launch_check(__func__);
+    }
     LAUNCH_RT24(k_res_stack16s, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
     return launch_check(__func__);
 }

@@ -679,6 +679,8 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
     static const int use_stack = getenv("DANCE_RES_STACK") ? atoi(getenv("DANCE_RES_STACK")) : 1;
     // opt-in (DANCE_HEAD_STACK=1): measured no faster than the two launches (experiments)
     static const int use_head_stack = getenv("DANCE_HEAD_STACK") ? atoi(getenv("DANCE_HEAD_STACK")) : 0;
+    // rings above 128 vertices: the 8-wave stack kernel (DANCE_RES_STACK_WIDE=0: one launch per block)
+    static const int use_stack_wide = getenv("DANCE_RES_STACK_WIDE") ? atoi(getenv("DANCE_RES_STACK_WIDE")) : 1;
     const bool head_stack = x_in == nullptr && use_stack && use_head_stack && v <= 128;
     if (head_stack) {
         // gather + head block + the 7 residual blocks in one launch; its time is booked on stage head
@@ -695,7 +697,7 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
     if (head_stack) {
         for (int i = 0; i < 7; ++i)
             DANCE_TRY(mark());
-    } else if (use_stack && v <= 128) {
+    } else if (use_stack && (v <= 128 || use_stack_wide)) {
         // one launch for the 7 residual blocks; its time is booked on stage res0
         DANCE_TRY(dance_res_stack16(net, state, sstride, slot, n, v, mfma_terms, stream));
         for (int i = 0; i < 7; ++i)

@@ -334,10 +334,10 @@ typedef struct dance_snake_net16 {
     int feat_channels;
 } dance_snake_net16;
 
-/* The 7 residual SnakeBlocks (res_* fields of the net) in one launch, v <= 128: state is the
+/* The 7 residual SnakeBlocks (res_* fields of the net) in one launch, v <= 256: state is the
  * (n, 8 slots) P16 block, slot 0 = head output (input), slots 1..7 receive the block outputs;
- * same results as 7 dance_conv16 calls (bit-identical), one kernel tail and launch gap
- * instead of 7.  reference: _SnakeNet.forward snake_head.py:262-268. */
+ * same results as 7 dance_conv16 calls (bit-identical up to 128 vertices; above, within 1e-5:
+ * another MFMA shape, hence summation order), one kernel tail and launch gap instead of 7.  reference: _SnakeNet.forward snake_head.py:262-268. */
 int dance_res_stack16(const dance_snake_net16 *net_host, void *state, int64_t stride, int64_t slot,
                       int n, int v, int mfma_terms, void *stream);
 

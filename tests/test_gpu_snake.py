@@ -271,10 +271,10 @@ def test_deterministic_and_chunked(device):
         assert coord_rel_err(a[i], want[i]) < REL_TOL
 
 
-@pytest.mark.parametrize("v", [16, 40, 64, 100, 128])
+@pytest.mark.parametrize("v", [16, 40, 64, 100, 128, 132, 196, 208, 224, 228, 256])
 def test_res_stack_equals_seven_launches(device, v):
-    """dance_res_stack16 (7 residual blocks, activations resident in LDS) is bit-identical to
-    7 dance_conv16 launches through HBM, for both MFMA term counts."""
+    """dance_res_stack16 (7 residual blocks, activations resident in LDS) against 7 dance_conv16
+    launches through HBM, for both MFMA term counts: bit-identical up to 128 vertices."""
     import ctypes
     from dance_amd._lib import check, current_stream, lib, ptr
     cfg, sd, _ = dance_state_dict(99, 128)
@@ -294,7 +294,16 @@ def test_res_stack_equals_seven_launches(device, v):
                                          s16.res_winv[i], s16.res_scale[i], s16.res_shift[i], None, 1, 1, 0,
                                          ptr(b[:, i + 1]), b.stride(0), slot, None, 0, n, v, 128, 128, 9,
                                          s16.dilation[i], terms, st), "conv16")
-        assert torch.equal(a, b), (v, terms)
+        if v <= 128:
+            assert torch.equal(a, b), (v, terms)
+        else:
+            # rings above 128 vertices: the stack runs 16x16x32 MFMAs, the per-block launches
+            # 32x32x16 ones -- same products, another summation order inside the matrix pipe
+            # (with one term per product the operands are plain fp16: a last-bit difference in
+            # one block flips roundings of the next block's inputs, 5e-4 each)
+            fa, fb = ops.from_p16(a), ops.from_p16(b)
+            rel = float((fa - fb).abs().max()) / float(fb.abs().max())
+            assert rel <= (1e-5 if terms == 3 else 5e-3), (v, terms, rel)
         assert bool(torch.isfinite(a.float()).all()) and float(a[:, 7].float().abs().max()) > 0
 
 
