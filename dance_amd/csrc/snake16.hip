@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
 // of the ring's 16-wide vertex tiles, the 128-channel image (115 / 132 KB) resident in LDS, one
 // workgroup per CU.  Same arithmetic per output element as k_conv16 / k_conv16s.
 template <int RT, int TERMS>
-__global__ __launch_bounds__(512) void k_res_stack16w(Stack16Args a, int n)
+__device__ __forceinline__ void res_stack16w_body(const Stack16Args &a, int n)
 {
     static_assert(RT == 7 || RT == 8, "rings of 129..256 vertices");
     constexpr int CBC = 8, NST = CBC / 4, AD = 2, NW = 8, CTW = RT, NB = (NST * CTW) % 4 == 0 ? 4 : 2;
@@ -892,6 +892,12 @@ __global__ __launch_bounds__(512) void k_res_stack16w(Stack16Args a, int n)
             __syncthreads();                    // image = block l + 1's input
         }
     }
+}
+
+template <int RT, int TERMS>
+__global__ __launch_bounds__(512) void k_res_stack16w(Stack16Args a, int n)
+{
+    res_stack16w_body<RT, TERMS>(a, n);
 }
 
 // fusion (1024 -> 256, max over the ring) + row constant + prediction[0] (1280 -> 256, ReLU)
