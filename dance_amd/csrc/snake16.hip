@@ -244,11 +244,11 @@ __device__ __forceinline__ void mfma16_core_s(f32x4 (&acc)[2][2 * RT], const cha
 // mfma16_core_s for rings above 128 vertices, where a wave owns only CTW of the ring's 16-wide
 // vertex tiles, starting at tile j0 (the vertex tiles are split over two groups of waves).
 // RTG sizes the LDS image (row stride 32 * RTG + 1 words).
-template <int RTG, int CTW, int NST, int AD, int NB, int TERMS>
+template <int RTG, int CTW, int NST, int AD, int NB, int TERMS, typename Hook>
 __device__ __forceinline__ void mfma16_core_sw(f32x4 (&acc)[2][CTW], const char *xs, unsigned lds0, int v,
                                                const char *wchunk, unsigned wlane, long long wps_b,
                                                long long wts_b, long long wstep_b, int taps, int dilation,
-                                               int c16, int q4, int j0)
+                                               int c16, int q4, int j0, Hook hook)
 {
     constexpr int CT = CTW, NT = NST * CT, DB = NB - 1, D = AD - 1;
     static_assert(NST % AD == 0 && D <= NST && D >= 1, "weight buffer rotation must close over a tap");
@@ -299,6 +299,8 @@ __device__ __forceinline__ void mfma16_core_sw(f32x4 (&acc)[2][CTW], const char 
                     DANCE_LOAD_A((s + D) % AD, wtap + (s + D) * wstep_b);
                 else if (more)
                     DANCE_LOAD_A((s + D) % AD, wtap + wts_b + (s + D - NST) * wstep_b);
+                if (tap == 0)
+                    hook(s);
             }
             DANCE_LOAD_B(q + DB);
             __builtin_amdgcn_sched_barrier(0);
@@ -822,6 +824,7 @@ __device__ __forceinline__ void res_stack16w_body(const Stack16Args &a, int n)
     const int v = a.v;
     const long long wbs_b = 128 * 16, wts_b = 16 * wbs_b, wps_b = 9 * wts_b;
     const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
+    auto nohook = [](int) __attribute__((always_inline)) {};
 
     for (long long nn = blockIdx.x; nn < n; nn += gridDim.x) {
         _Float16 *sn = a.state + nn * a.stride;
@@ -850,7 +853,7 @@ __device__ __forceinline__ void res_stack16w_body(const Stack16Args &a, int n)
 #pragma unroll 1
             for (int c = 0; c < 2; ++c)
                 mfma16_core_sw<RT, CTW, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b,
-                                                            wlane, wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, j0);
+                                                            wlane, wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, j0, nohook);
             __syncthreads();                    // every wave has read the whole image
             int ce = c16, qe = q4;
             asm volatile("" : "+v"(ce), "+v"(qe));

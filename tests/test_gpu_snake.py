@@ -378,3 +378,33 @@ def test_head_stack_equals_separate_launches(device, v):
         assert torch.equal(a, bb), (v, terms)
         assert torch.equal(att_a, att_b)
         assert bool(torch.isfinite(a.float()).all()) and float(a[:, 7].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("v", [64, 128, 132, 196, 224, 256])
+def test_conv16_pointwise_forms(device, v):
+    """dance_conv16 as the k=1 Conv1d's of the snake net in the fast mode -- fusion + max over the
+    ring, prediction[0] with a per-contour row constant, prediction[1] (64 outputs, fp32 out) --
+    against torch fp32; above 128 vertices these run the 8-wave k_conv16w."""
+    g = torch.Generator().manual_seed(v)
+    n = 7
+    x = torch.randn((n, 1024, v), generator=g)
+    w = torch.randn((256, 1024, 1), generator=g) / 32
+    b = torch.randn((256,), generator=g)
+    x16 = ops.to_p16(x.to(device))
+    w16, s = ops.pack_conv_weight16(w.to(device))
+    want = torch.nn.functional.conv1d(x, w, b)
+    scale = float(want.abs().max())
+    m = ops.conv16(x16, w16, s, b.to(device), cin=1024, cout=256, v=v, maxv=True)
+    assert rel_err(m, want.max(dim=2)[0], floor=scale) < 1e-5
+    h = torch.randn((n, 256), generator=g)
+    y = ops.conv16(x16, w16, s, None, cin=1024, cout=256, v=v, rowinit=h.to(device), relu=True)
+    want2 = torch.relu(torch.nn.functional.conv1d(x, w) + h[:, :, None])
+    assert rel_err(ops.from_p16(y), want2, floor=scale) < 1e-5
+    w64 = torch.randn((64, 256, 1), generator=g) / 16
+    x256 = torch.randn((n, 256, v), generator=g)
+    w64p, s64 = ops.pack_conv_weight16(w64.to(device))
+    y64 = ops.conv16(ops.to_p16(x256.to(device)), w64p, s64, b[:64].to(device), cin=256, cout=64, v=v,
+                     relu=True, out_f32=True)
+    want3 = torch.relu(torch.nn.functional.conv1d(x256, w64, b[:64]))
+    assert y64.shape == (n, 64, v)
+    assert rel_err(y64, want3, floor=float(want3.abs().max())) < 1e-5
