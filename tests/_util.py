@@ -68,6 +68,20 @@ class FakeBoxes:
     def __init__(self, tensor):
         self.tensor = tensor
 
+    def scale(self, scale_x, scale_y):
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
+    def nonempty(self, threshold=0):
+        b = self.tensor
+        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+
+    def __getitem__(self, item):
+        return FakeBoxes(self.tensor[item])
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
     def clip(self, box_size):
         h, w = box_size
         self.tensor[:, 0].clamp_(min=0, max=w)
@@ -91,6 +105,12 @@ class FakeInstances:
 
     def has(self, name):
         return name in self._fields
+
+    def get_fields(self):
+        return {k: getattr(self, k) for k in self._fields}
+
+    def __getitem__(self, item):
+        return FakeInstances(self.image_size, **{k: v[item] for k, v in self.get_fields().items()})
 
 
 EDGE_HEAD_LEVELS = (("p2", 4), ("p3", 8), ("p4", 16), ("p5", 32))

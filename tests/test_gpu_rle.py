@@ -175,3 +175,37 @@ def test_errors(device):
         rle.polygon_rle(torch.zeros((1, 4, 2), device=device, dtype=torch.float64), (10, 10))
     with pytest.raises(RuntimeError, match="image shape"):
         rle.polygon_rle(torch.zeros((1, 4, 2), device=device), (0, 10))
+
+
+def test_detector_postprocess_makes_the_masks_on_the_gpu(device):
+    """dsnake_baseline/postprocessing.py:24-76 through dance_amd.postprocessing: boxes and contours
+    scaled to the output resolution, clipped, empty boxes dropped, pred_masks = RLE dicts."""
+    from _util import FakeBoxes, FakeInstances
+    from dance_amd import postprocessing
+    from dance_amd.structures import PolygonPoints
+    h, w, oh, ow = 200, 304, 480, 640
+    polys = star_polygons(9, 64, h, w, seed=4, spill=0.2)
+    boxes = torch.cat([polys.min(1)[0], polys.max(1)[0]], 1)
+    boxes[2] = torch.tensor([50.0, 60.0, 50.0, 90.0])                      # empty after clipping -> dropped
+    scores = torch.arange(9, dtype=torch.float32)
+    inst = FakeInstances((h, w), pred_boxes=FakeBoxes(boxes.to(device)), scores=scores.to(device),
+                         pred_polys=PolygonPoints(polys.to(device)))
+    out = postprocessing.detector_postprocess(inst, oh, ow)
+    keep = [i for i in range(9) if i != 2]
+    assert out.image_size == (oh, ow) and out.scores.cpu().tolist() == [float(i) for i in keep]
+    want = polys[keep].clone()
+    want[..., 0] *= ow / w
+    want[..., 1] *= oh / h
+    want[..., 0].clamp_(0, ow)
+    want[..., 1].clamp_(0, oh)
+    assert torch.equal(out.pred_polys.tensor.cpu(), want)
+    assert out.pred_masks == rle_ref.get_polygon_rles(want.flatten(1).numpy(), (oh, ow))
+    # the DANCE variant: no clipping of the contours, no masks, optional boxes from the contours
+    inst = FakeInstances((h, w), pred_boxes=FakeBoxes(boxes.to(device)), scores=scores.to(device),
+                         pred_polys=PolygonPoints(polys.to(device)))
+    out = postprocessing.dance_detector_postprocess(False, 0.0, "poly", inst, oh, ow, 0, False, True)
+    raw = polys[keep].clone()
+    raw[..., 0] *= ow / w
+    raw[..., 1] *= oh / h
+    assert torch.equal(out.pred_polys.tensor.cpu(), raw) and not out.has("pred_masks")
+    assert torch.equal(out.pred_boxes.tensor.cpu(), torch.cat([raw.min(1)[0], raw.max(1)[0]], 1))
