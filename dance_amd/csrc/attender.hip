@@ -7,10 +7,10 @@
 // Small maps, tiny channel counts: fp32 FMA on the vector ALU (9.2 k MAC per pixel in the
 // middle layer), no MFMA reshaping.  GroupNorm needs whole-image statistics, so three launches:
 //   k_att_stats1  conv1 evaluated per pixel (9 MAC x 32), only its group sums are kept;
-//   k_att_conv2   per 32x8 tile: conv1 recomputed with halo -> GN1 -> ReLU into LDS, conv2
+//   k_att_conv2   per 32x16 tile: conv1 recomputed with halo -> GN1 -> ReLU into LDS, conv2
 //                 with the weights as scalar operands (uniform s_loads of the [c][tap][o]
 //                 packing), raw output (B,32,H,W) + group sums;
-//   k_att_out     per tile: GN2 -> ReLU of the raw output with halo into LDS, conv3 + bias ->
+//   k_att_out     per 32x16 tile: GN2 -> ReLU of the raw output with halo into LDS, conv3 + bias ->
 //                 sigmoid -> the attention plane the gather kernels read.
 // Group sums are fp32 per thread -> wave shuffle -> workgroup (LDS) -> one fp64 atomic per value.
 #include "common.h"
@@ -19,9 +19,9 @@ using dance::launch_check;
 
 namespace {
 
-constexpr int AT_C = 32, AT_G = 4, AT_TX = 32, AT_TY = 8;
-constexpr int AT_HX = AT_TX + 2, AT_HY = AT_TY + 2;             // act tile with halo 1
-constexpr int AT_XX = AT_TX + 4, AT_XY = AT_TY + 4;             // x tile with halo 2
+constexpr int AT_C = 32, AT_G = 4, AT_TX = 32;
+constexpr int AT_HX = AT_TX + 2;                                // act tile with halo 1 (columns)
+constexpr int AT_XX = AT_TX + 4;                                // x tile with halo 2 (columns)
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -120,19 +120,24 @@ __global__ __launch_bounds__(256) void k_att_stats1(const float *__restrict__ x,
     gs.flush(stats1 + (long long)b * AT_G * 2, red, threadIdx.x);
 }
 
+// conv2 tile: 32 x 16 pixels, two pixels (rows ty and ty + 8) per thread so that every scalar
+// weight load feeds two FMAs and the halo is 20 % instead of 33 %; the layer-1 activations go
+// through LDS 16 channels at a time (39 KB: three workgroups per CU).
+constexpr int AT_TY2 = 16, AT_HY2 = AT_TY2 + 2, AT_XY2 = AT_TY2 + 4, AT_CH = 16;
+
 __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, const float *__restrict__ w1,
                                                    const float *__restrict__ g1, const float *__restrict__ b1,
                                                    const double *__restrict__ stats1,
                                                    const float *__restrict__ w2p, float *__restrict__ y2,
                                                    double *__restrict__ stats2, float eps, int h, int w)
 {
-    __shared__ float xt[AT_XY][AT_XX];
-    __shared__ float act[AT_C][AT_HY][AT_HX];
+    __shared__ float xt[AT_XY2][AT_XX];
+    __shared__ float act[AT_CH][AT_HY2][AT_HX];
     __shared__ float ga[AT_C], gb[AT_C], red[32];
-    const int b = blockIdx.z, x0 = blockIdx.x * AT_TX, y0 = blockIdx.y * AT_TY;
+    const int b = blockIdx.z, x0 = blockIdx.x * AT_TX, y0 = blockIdx.y * AT_TY2;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     const float *xb = x + (long long)b * h * w;
-    for (int i = t; i < AT_XY * AT_XX; i += 256) {
+    for (int i = t; i < AT_XY2 * AT_XX; i += 256) {
         const int r = i / AT_XX, c = i - r * AT_XX;
         xt[r][c] = px(xb, h, w, y0 + r - 2, x0 + c - 2);
     }
@@ -140,23 +145,31 @@ __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, 
         gn_affine(stats1 + (long long)b * AT_G * 2, g1, b1, (double)(AT_C / AT_G) * h * w, eps, t, ga[t], gb[t]);
     __syncthreads();
     // layer 1 on the halo tile: conv1 -> GN1 -> ReLU; zero outside the image (conv2's padding).
-    // A thread keeps the 3x3 input patch of its (up to two) tile positions in registers and
+    // A thread keeps the 3x3 input patches of its (up to three) tile positions in registers and
     // walks the channels with uniform (scalar) weights.
-    {
-        constexpr int NPOS = AT_HY * AT_HX, ROUNDS = (NPOS + 255) / 256;
-        float nb[ROUNDS][9];
-        bool in[ROUNDS];
+    constexpr int NPOS = AT_HY2 * AT_HX, ROUNDS = (NPOS + 255) / 256;
+    float nb[ROUNDS][9];
+    bool in[ROUNDS];
 #pragma unroll
-        for (int j = 0; j < ROUNDS; ++j) {
-            const int pos = min(t + j * 256, NPOS - 1), r = pos / AT_HX, q = pos - r * AT_HX;
-            const int yy = y0 + r - 1, xx = x0 + q - 1;
-            in[j] = yy >= 0 && yy < h && xx >= 0 && xx < w;
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int pos = min(t + j * 256, NPOS - 1), r = pos / AT_HX, q = pos - r * AT_HX;
+        const int yy = y0 + r - 1, xx = x0 + q - 1;
+        in[j] = yy >= 0 && yy < h && xx >= 0 && xx < w;
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
-                nb[j][k] = xt[r + k / 3][q + k % 3];
-        }
+        for (int k = 0; k < 9; ++k)
+            nb[j][k] = xt[r + k / 3][q + k % 3];
+    }
+    float acc[2][AT_C];
+#pragma unroll
+    for (int o = 0; o < AT_C; ++o)
+        acc[0][o] = acc[1][o] = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < AT_C; c0 += AT_CH) {
+        if (c0)
+            __syncthreads();                    // the previous 16 channels have been consumed
 #pragma unroll 2
-        for (int c = 0; c < AT_C; ++c) {
+        for (int cc = 0; cc < AT_CH; ++cc) {
+            const int c = c0 + cc;
             const float a = ga[c], bb = gb[c];
 #pragma unroll
             for (int j = 0; j < ROUNDS; ++j) {
@@ -165,40 +178,42 @@ __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, 
                 for (int k = 0; k < 9; ++k)
                     s = fmaf(w1[c * 9 + k], nb[j][k], s);
                 if (t + j * 256 < NPOS)
-                    (&act[c][0][0])[t + j * 256] = in[j] ? fmaxf(fmaf(s, a, bb), 0.f) : 0.f;
+                    (&act[cc][0][0])[t + j * 256] = in[j] ? fmaxf(fmaf(s, a, bb), 0.f) : 0.f;
             }
         }
-    }
-    __syncthreads();
-    float acc[AT_C];
-#pragma unroll
-    for (int o = 0; o < AT_C; ++o)
-        acc[o] = 0.f;
+        __syncthreads();
 #pragma unroll 1
-    for (int c = 0; c < AT_C; ++c) {
-        float a[9];
+        for (int cc = 0; cc < AT_CH; ++cc) {
+            float a0[9], a1[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-            a[k] = act[c][ty + k / 3][tx + k % 3];
-        const float *wc = w2p + c * 9 * AT_C;               // uniform: scalar loads
+            for (int k = 0; k < 9; ++k) {
+                a0[k] = act[cc][ty + k / 3][tx + k % 3];
+                a1[k] = act[cc][ty + 8 + k / 3][tx + k % 3];
+            }
+            const float *wc = w2p + (c0 + cc) * 9 * AT_C;       // uniform: scalar loads
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+            for (int k = 0; k < 9; ++k)
 #pragma unroll
-            for (int o = 0; o < AT_C; ++o)
-                acc[o] = fmaf(wc[k * AT_C + o], a[k], acc[o]);
-    }
-    const int yy = y0 + ty, xx = x0 + tx;
-    const bool valid = yy < h && xx < w;
-    if (valid) {
-        float *dst = y2 + (long long)b * AT_C * h * w + (long long)yy * w + xx;
-#pragma unroll
-        for (int o = 0; o < AT_C; ++o)
-            dst[(long long)o * h * w] = acc[o];
+                for (int o = 0; o < AT_C; ++o) {
+                    const float wv = wc[k * AT_C + o];
+                    acc[0][o] = fmaf(wv, a0[k], acc[0][o]);
+                    acc[1][o] = fmaf(wv, a1[k], acc[1][o]);
+                }
+        }
     }
     GroupSums gs;
     gs.clear();
-    if (valid)
-        gs.add(acc);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int yy = y0 + ty + 8 * p, xx = x0 + tx;
+        if (yy < h && xx < w) {
+            float *dst = y2 + (long long)b * AT_C * h * w + (long long)yy * w + xx;
+#pragma unroll
+            for (int o = 0; o < AT_C; ++o)
+                dst[(long long)o * h * w] = acc[p][o];
+            gs.add(acc[p]);
+        }
+    }
     gs.flush(stats2 + (long long)b * AT_G * 2, red, t);
 }
 
@@ -207,33 +222,53 @@ __global__ __launch_bounds__(256) void k_att_out(const float *__restrict__ y2, c
                                                  const float *__restrict__ w3, const float *__restrict__ bias3,
                                                  float *__restrict__ att, float eps, int h, int w)
 {
-    __shared__ float act[AT_C][AT_HY][AT_HX];
+    // same 32 x 16 tile, two pixels per thread, 16 channels at a time through LDS
+    __shared__ float act[AT_CH][AT_HY2][AT_HX];
     __shared__ float ga[AT_C], gb[AT_C];
-    const int b = blockIdx.z, x0 = blockIdx.x * AT_TX, y0 = blockIdx.y * AT_TY;
+    const int b = blockIdx.z, x0 = blockIdx.x * AT_TX, y0 = blockIdx.y * AT_TY2;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     if (t < AT_C)
         gn_affine(stats2 + (long long)b * AT_G * 2, g2, b2, (double)(AT_C / AT_G) * h * w, eps, t, ga[t], gb[t]);
-    __syncthreads();
     const float *yb = y2 + (long long)b * AT_C * h * w;
-    for (int i = t; i < AT_C * AT_HY * AT_HX; i += 256) {
-        const int c = i / (AT_HY * AT_HX), rem = i - c * (AT_HY * AT_HX), r = rem / AT_HX, q = rem - r * AT_HX;
-        const int yy = y0 + r - 1, xx = x0 + q - 1;
-        float v = 0.f;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w)
-            v = fmaxf(fmaf(yb[(long long)c * h * w + (long long)yy * w + xx], ga[c], gb[c]), 0.f);
-        act[c][r][q] = v;
-    }
-    __syncthreads();
-    const int yy = y0 + ty, xx = x0 + tx;
-    if (yy >= h || xx >= w)
-        return;
-    float s = bias3[0];
-#pragma unroll 4
-    for (int c = 0; c < AT_C; ++c)
+    constexpr int NPOS = AT_HY2 * AT_HX, ROUNDS = (NPOS + 255) / 256;
+    long long off[ROUNDS];                      // pixel offset of this thread's tile positions (-1: outside)
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
-            s = fmaf(w3[c * 9 + k], act[c][ty + k / 3][tx + k % 3], s);
-    att[(long long)b * h * w + (long long)yy * w + xx] = 1.0f / (1.0f + expf(-s));
+    for (int j = 0; j < ROUNDS; ++j) {
+        const int pos = min(t + j * 256, NPOS - 1), r = pos / AT_HX, q = pos - r * AT_HX;
+        const int yy = y0 + r - 1, xx = x0 + q - 1;
+        off[j] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (long long)yy * w + xx : -1;
+    }
+    float s0 = bias3[0], s1 = s0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < AT_C; c0 += AT_CH) {
+        __syncthreads();                        // ga / gb ready; the previous 16 channels consumed
+#pragma unroll 4
+        for (int cc = 0; cc < AT_CH; ++cc) {
+            const int c = c0 + cc;
+            const float a = ga[c], bb = gb[c];
+#pragma unroll
+            for (int j = 0; j < ROUNDS; ++j)
+                if (t + j * 256 < NPOS)
+                    (&act[cc][0][0])[t + j * 256] =
+                        off[j] >= 0 ? fmaxf(fmaf(yb[(long long)c * h * w + off[j]], a, bb), 0.f) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int cc = 0; cc < AT_CH; ++cc)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float wv = w3[(c0 + cc) * 9 + k];
+                s0 = fmaf(wv, act[cc][ty + k / 3][tx + k % 3], s0);
+                s1 = fmaf(wv, act[cc][ty + 8 + k / 3][tx + k % 3], s1);
+            }
+    }
+    const int xx = x0 + tx;
+    if (xx < w) {
+        if (y0 + ty < h)
+            att[(long long)b * h * w + (long long)(y0 + ty) * w + xx] = 1.0f / (1.0f + expf(-s0));
+        if (y0 + ty + 8 < h)
+            att[(long long)b * h * w + (long long)(y0 + ty + 8) * w + xx] = 1.0f / (1.0f + expf(-s1));
+    }
 }
 
 }  // namespace
@@ -263,10 +298,10 @@ extern "C" int dance_attender(const float *x, const float *w1, const float *gn1_
     hipError_t e = hipMemsetAsync(stats1, 0, (size_t)2 * b * AT_G * 2 * 8, s);
     if (e != hipSuccess)
         return dance::fail((int)e, __func__, hipGetErrorString(e));
-    const dim3 tiles(dance::ceil_div(w, AT_TX), dance::ceil_div(h, AT_TY), b);
     hipLaunchKernelGGL(k_att_stats1, dim3(dance::ceil_div(h * w, 256 * AT_PPT), b), dim3(256), 0, s, x, w1, stats1, h, w);
-    hipLaunchKernelGGL(k_att_conv2, tiles, dim3(256), 0, s, x, w1, gn1_w, gn1_b, stats1, w2_packed, y2, stats2, eps,
+    const dim3 tiles2(dance::ceil_div(w, AT_TX), dance::ceil_div(h, AT_TY2), b);
+    hipLaunchKernelGGL(k_att_conv2, tiles2, dim3(256), 0, s, x, w1, gn1_w, gn1_b, stats1, w2_packed, y2, stats2, eps,
                        h, w);
-    hipLaunchKernelGGL(k_att_out, tiles, dim3(256), 0, s, y2, gn2_w, gn2_b, stats2, w3, b3, att, eps, h, w);
+    hipLaunchKernelGGL(k_att_out, tiles2, dim3(256), 0, s, y2, gn2_w, gn2_b, stats2, w3, b3, att, eps, h, w);
     return launch_check(__func__);
 }
