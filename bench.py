@@ -245,10 +245,14 @@ def main():
             layers = net2._bottom_hip_layers(dev)
 
             def stock():
-                x = feats[:, 1:].contiguous(memory_format=torch.channels_last)
-                for conv in net2.bottom_out:
-                    x = conv(x)
-                return x.permute(0, 2, 3, 1).contiguous()
+                modules._ConvNormAct.use_hip = False             # the plain torch.nn ops (MIOpen)
+                try:
+                    x = feats[:, 1:].contiguous(memory_format=torch.channels_last)
+                    for conv in net2.bottom_out:
+                        x = conv(x)
+                    return x.permute(0, 2, 3, 1).contiguous()
+                finally:
+                    modules._ConvNormAct.use_hip = True
 
             def timed(fn, reps):
                 for _ in range(2):

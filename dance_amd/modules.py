@@ -74,14 +74,41 @@ class _SnakeNet(nn.Module):
 
 class _ConvNormAct(nn.Conv2d):
     """conv3x3 (+ GroupNorm) + ReLU with detectron2.layers.Conv2d's state-dict keys
-    (`weight`, `norm.weight`, `norm.bias`)."""
+    (`weight`, `norm.weight`, `norm.bias`).  In eval mode on the GPU the shipped shape
+    (C -> C, C % 128 == 0, GroupNorm(32), no bias, dilation 1) runs on the feature-prep kernels
+    (conv3x3 as split-half f16 MFMA implicit GEMM + GroupNorm + ReLU; output in
+    channels_last memory); anything else, `DANCE_FEATPREP=torch`, or `use_hip = False` runs
+    the stock torch.nn ops."""
+
+    use_hip = True
 
     def __init__(self, cin, cout, dilation, norm):
         super().__init__(cin, cout, kernel_size=3, stride=1, padding=1, dilation=dilation,
                          bias=not norm)
         self.norm = nn.GroupNorm(32, cout) if norm == "GN" else None
 
+    def hip_layer(self, dev):
+        """(w16, scale, gamma, beta) for ops.bottom_out16, or None when the HIP kernels do not
+        cover this layer."""
+        if (self.norm is None or self.bias is not None or self.dilation != (1, 1)
+                or self.in_channels != self.out_channels or self.in_channels % 128 != 0
+                or self.norm.num_groups != 32):
+            return None
+        sig = (dev,) + tuple(int(p._version) for p in self.parameters())
+        if getattr(self, "_hip_sig", None) != sig:
+            w16, s = ops.pack_conv3x3_weight16(self.weight.detach().float())
+            self._hip_packed = (w16, s, self.norm.weight.detach().float().contiguous(),
+                                self.norm.bias.detach().float().contiguous())
+            self._hip_sig = sig
+        return self._hip_packed
+
     def forward(self, x):
+        if (self.use_hip and x.is_cuda and not self.training and not torch.is_grad_enabled()
+                and os.environ.get("DANCE_FEATPREP", "hip") == "hip"
+                and os.environ.get("DANCE_PRECISION", "fp16x3") == "fp16x3"):
+            layer = self.hip_layer(x.device)
+            if layer is not None:
+                return ops.bottom_out16(x, 0, [layer], groups=32, eps=self.norm.eps).permute(0, 3, 1, 2)
         x = super().forward(x)
         if self.norm is not None:
             x = self.norm(x)
@@ -161,19 +188,8 @@ class _SnakeHeadBase(nn.Module):
         is outside what they cover (then the stock torch.nn modules run)."""
         if os.environ.get("DANCE_FEATPREP", "hip") != "hip" or os.environ.get("DANCE_PRECISION", "fp16x3") != "fp16x3":
             return None
-        for m in self.bottom_out:
-            if (m.norm is None or m.bias is not None or m.dilation != (1, 1) or m.in_channels != m.out_channels
-                    or m.in_channels % 128 != 0 or m.norm.num_groups != 32):
-                return None
-        sig = (dev,) + tuple(int(p._version) for m in self.bottom_out for p in m.parameters())
-        if getattr(self, "_bottom_sig", None) != sig:
-            layers = []
-            for m in self.bottom_out:
-                w16, s = ops.pack_conv3x3_weight16(m.weight.detach().float())
-                layers.append((w16, s, m.norm.weight.detach().float().contiguous(),
-                               m.norm.bias.detach().float().contiguous()))
-            self._bottom_layers, self._bottom_sig = layers, sig
-        return self._bottom_layers
+        layers = [m.hip_layer(dev) for m in self.bottom_out]
+        return None if any(l is None for l in layers) else layers
 
     def _bottom(self, feats_all, c_off):
         """bottom_out (snake_head.py:1816-1820) on channels [c_off:] of the NCHW input; returns
@@ -464,8 +480,10 @@ class EdgeSnakeFPNHead(nn.Module):
         return att_map, {}, new_instances                     :392-395
 
     Same constructor `(cfg, input_shape)` and state-dict keys (`attender.*`, `p2.0.*` ... `p5.4.*`,
-    `predictor.*`, `refine_head.*`).  The semantic-FPN 2-D convolutions stay stock PyTorch-ROCm
-    (boundary / caller); the concatenation is not materialised."""
+    `predictor.*`, `refine_head.*`).  The semantic-FPN head stays torch.nn modules (SURVEY.md
+    section 2: boundary / caller) -- its 256 -> 256 conv3x3 + GroupNorm + ReLU layers route to the
+    feature-prep kernels in eval mode (_ConvNormAct), the first layer of each level, the upsampling,
+    the sum and the 1x1 predictor are stock ops; the concatenation is not materialised."""
 
     def __init__(self, cfg, input_shape, polygon_cls=PolygonPoints):
         super().__init__()
