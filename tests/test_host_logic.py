@@ -88,3 +88,38 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+
+
+def test_new_wrappers_refuse_cpu_tensors_and_bad_shapes():
+    """No CPU / torch fallback anywhere: the host wrappers of the widened rows raise."""
+    import pytest
+    import torch
+    from dance_amd import modules, rle
+    with pytest.raises(RuntimeError, match="GPU"):
+        rle.polygon_rle(torch.zeros((2, 8, 2)), (32, 32))
+    with pytest.raises(RuntimeError, match="GPU"):
+        rle.get_polygon_rles(torch.zeros((2, 16)), (32, 32))
+    with pytest.raises(RuntimeError, match="GPU"):
+        modules.Attender()(torch.zeros((1, 1, 8, 8)))
+    att = modules.Attender()
+    assert list(att.state_dict()) == ["0.weight", "0.norm.weight", "0.norm.bias", "1.weight", "1.norm.weight",
+                                      "1.norm.bias", "2.weight", "2.bias"]
+
+
+def test_edge_head_refuses_unbuilt_options():
+    import pytest
+    from _util import edge_head_cfg
+    from dance_amd import modules
+    cfg, shapes = edge_head_cfg()
+    cfg.MODEL.SNAKE_HEAD.SELECTIVE_REFINE = True
+    with pytest.raises(NotImplementedError, match="SELECTIVE_REFINE"):
+        modules.EdgeSnakeFPNHead(cfg, shapes)
+    cfg, shapes = edge_head_cfg()
+    cfg.TEST.GT_IN.ON = True
+    with pytest.raises(NotImplementedError, match="GT_IN"):
+        modules.EdgeSnakeFPNHead(cfg, shapes)
+    cfg, shapes = edge_head_cfg()
+    head = modules.EdgeSnakeFPNHead(cfg, shapes)
+    keys = list(head.state_dict())
+    assert keys[0] == "attender.0.weight" and "p5.4.norm.bias" in keys and "predictor.1.bias" in keys
+    assert keys.index("p2.0.weight") < keys.index("predictor.0.weight") < keys.index("refine_head.bottom_out.0.weight")
