@@ -206,6 +206,26 @@ def main():
         if args.streams > 1:
             events = events_full
 
+    # the same steps with the contours split over two HIP streams (bit-identical results; one
+    # half's kernel tails and launch gaps overlap the other half's kernels).  Reported beside
+    # the headline, never as it: per-kernel event timing is only meaningful on one stream.
+    two_streams = None
+    if rank == 0 and world == 1 and args.streams == 1:
+        def step2():
+            f = deformer.prepare_features(feats) if pre is None else pre
+            return deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", streams=2)[-1]
+        for _ in range(2):
+            out2 = step2()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            out2 = step2()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        assert torch.equal(out2, out[:n]), "two-stream deformation differs from the single-stream one"
+        two_streams = {"value": n * args.steps / dt2, "unit": "contours/s", "ms_per_step": dt2 / args.steps * 1e3,
+                       "note": "deform(..., streams=2) / DANCE_STREAMS=2, same steps, results bit-identical"}
+
     # the gather stage on its own (k_gather: 4 taps x 257 channels per vertex -> (N, 258, V)),
     # outside the timed region: the HBM-bound form of the stage that k_gather_head* fuses
     gather_alone_ms = None
@@ -461,6 +481,7 @@ def main():
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms,
                              note="instrumented pass after the timed region (14 events per iteration)"),
             "streams": args.streams,
+            "two_streams": two_streams,
             "feat_prep": feat_prep,
             "mask_rle": mask_rle,
             "attender": attender_fig,
