@@ -48,7 +48,7 @@ def measured_traffic(kernel, workgroups):
         return None, None
     for key, val in t["kernels"].items():
         name, wg = key.split("|")
-        if name.startswith(kernel) and int(wg) == workgroups:
+        if (name == kernel[:-1] if kernel.endswith("|") else name.startswith(kernel)) and int(wg) == workgroups:
             return val["bytes"], t["source"]
     return None, None
 
@@ -472,6 +472,12 @@ def main():
                        "note": "the fused kernel is MFMA-bound (%d MFLOP per 526 KB gathered per "
                                "contour-iteration), not HBM-bound" % (
                                    2.0 * ((CH + 2) * 128 * 9 + (7 * MACS_RES_BLOCK if head_stack else 0)) * v / 1e6),
+                       "traffic": measured_traffic("k_head_stack16s" if head_stack else
+                                                   "k_gather_head16" if args.precision != "fp32" else "k_gather_head<", n)[0],
+                       "standalone_traffic": measured_traffic("k_gather|", 4 * n)[0] if v == 128 else None,
+                       "traffic_note": "HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json; "
+                                       "neighbouring vertices share taps in L2, so fewer bytes are fetched than the "
+                                       "no-reuse algorithmic figure)",
                        "standalone_kernel": "k_gather (gather + de_location + concat only, untimed extra)",
                        "standalone_ms": gather_alone_ms,
                        "standalone_algorithmic_GBps": GATHER_BYTES_PER_VERTEX * v * n / (gather_alone_ms * 1e-3) / 1e9,
