@@ -66,6 +66,7 @@ SIGNATURES = {
     "dance_conv3x3_16": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_nms_sorted": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "dance_nms_sorted_plain": (c_int, [P, c_int, c_float, P, P, P, P]),
     "dance_contour_upsample_2x": (c_int, [P, P, c_int, c_int, P]),
     "dance_attender_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dance_attender": (c_int, [P, P, P, P, P, P, P, P, P, c_float, P, P, c_int64, c_int, c_int, c_int, P]),

@@ -307,19 +307,29 @@ extern "C" int dance_roll_array(const float *array, const int64_t *step, float *
 // nms (utils.h:36-43, nms.cu:13-128): IoU bit mask over 64 x 64 tiles of the score-sorted
 // boxes, then the greedy sweep -- on the device (the reference copies the mask to the host).
 // ------------------------------------------------------------------------------------
+// one = 1: the reference kernel's "+1" pixel convention (nms.cu:13-21); one = 0: the continuous
+// convention of torchvision.ops.nms, which the reference's ml_nms reaches through detectron2
+template <int ONE>
 __device__ __forceinline__ float nms_iou(const float *a, const float *b)
 {
     const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
     const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-    const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+    float width = right - left, height = bottom - top, wa = a[2] - a[0], ha = a[3] - a[1], wb = b[2] - b[0],
+          hb = b[3] - b[1];
+    if (ONE) {
+        width += 1; height += 1; wa += 1; ha += 1; wb += 1; hb += 1;
+    }
+    width = fmaxf(width, 0.f);
+    height = fmaxf(height, 0.f);
     const float interS = width * height;
-    const float Sa = (a[2] - a[0] + 1) * (a[3] - a[1] + 1);
-    const float Sb = (b[2] - b[0] + 1) * (b[3] - b[1] + 1);
+    const float Sa = wa * ha;
+    const float Sb = wb * hb;
     return interS / (Sa + Sb - interS);
 }
 
 // grid (col_blocks, col_blocks), 64 threads; mask[i][col] bit j = IoU(box i, box 64 col + j) > thresh
 // for j later than i in the sorted order (nms.cu:23-67)
+template <int ONE>
 __global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float *__restrict__ boxes,
                                                  unsigned long long *__restrict__ mask)
 {
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const floa
         unsigned long long t = 0;
         const int start = row_start == col_start ? threadIdx.x + 1 : 0;
         for (int i = start; i < col_size; ++i)
-            if (nms_iou(cb, bb + i * 5) > thresh)
+            if (nms_iou<ONE>(cb, bb + i * 5) > thresh)
                 t |= 1ULL << i;
         mask[(long long)cur * gridDim.x + col_start] = t;
     }
@@ -381,8 +391,23 @@ __global__ __launch_bounds__(64) void k_nms_sweep(int n, int col_blocks, const u
         *count = num;
 }
 
+static int nms_sorted_impl(const float *boxes_sorted, int n, float thresh, int plus_one, uint64_t *mask_ws,
+                           int64_t *keep, int32_t *count, void *stream);
+
 extern "C" int dance_nms_sorted(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
                                 int64_t *keep, int32_t *count, void *stream)
+{
+    return nms_sorted_impl(boxes_sorted, n, thresh, 1, mask_ws, keep, count, stream);
+}
+
+extern "C" int dance_nms_sorted_plain(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
+                                      int64_t *keep, int32_t *count, void *stream)
+{
+    return nms_sorted_impl(boxes_sorted, n, thresh, 0, mask_ws, keep, count, stream);
+}
+
+static int nms_sorted_impl(const float *boxes_sorted, int n, float thresh, int plus_one, uint64_t *mask_ws,
+                           int64_t *keep, int32_t *count, void *stream)
 {
     DANCE_REQUIRE(n >= 0 && n <= (1 << 20));
     DANCE_REQUIRE(count != nullptr);
@@ -392,7 +417,10 @@ extern "C" int dance_nms_sorted(const float *boxes_sorted, int n, float thresh, 
     DANCE_REQUIRE(boxes_sorted && mask_ws && keep);
     const int cb = (n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)mask_ws;
-    hipLaunchKernelGGL(k_nms_mask, dim3(cb, cb), dim3(64), 0, (hipStream_t)stream, n, thresh, boxes_sorted, mask);
+    if (plus_one)
+        hipLaunchKernelGGL(k_nms_mask<1>, dim3(cb, cb), dim3(64), 0, (hipStream_t)stream, n, thresh, boxes_sorted, mask);
+    else
+        hipLaunchKernelGGL(k_nms_mask<0>, dim3(cb, cb), dim3(64), 0, (hipStream_t)stream, n, thresh, boxes_sorted, mask);
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, (hipStream_t)stream, n, cb, mask,
                        mask + (long long)n * cb, (long long *)keep, count);
     return launch_check(__func__);

@@ -66,6 +66,13 @@ int dance_roll_array(const float *array, const int64_t *step, float *new_array, 
 int dance_nms_sorted(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
                      int64_t *keep, int32_t *count, void *stream);
 
+/* The same with the IoU of torchvision.ops.nms (widths / heights without the "+1"): the kernel
+ * behind detectron2.layers.batched_nms, which the reference's multi-class `ml_nms` calls
+ * (core/layers/ml_nms.py:25, used at fcose_outputs.py:528; dance_amd.ml_nms.ml_nms moves the
+ * classes apart by a coordinate offset first, as torchvision does). */
+int dance_nms_sorted_plain(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
+                           int64_t *keep, int32_t *count, void *stream);
+
 /* reference: snake_head.py:1752-1761 (`RefineNet.contour_upsample_2x`, used only with
  * LAST_UP_SAMPLE).  loc (n,v,2) f32 -> out (n,2v,2): even slots copy, odd slots are the
  * mid-points (p[i] + p[i+1 mod v]) / 2, rounded as the reference's add-then-divide. */

@@ -216,6 +216,40 @@ static float ref_iou(const float *a, const float *b)
     return interS / (Sa + Sb - interS);
 }
 
+/* The same sweep with the IoU of torchvision.ops.nms -- what detectron2.layers.batched_nms, the
+ * call behind the reference's ml_nms (core/layers/ml_nms.py:25, fcose_outputs.py:528), runs:
+ * widths and heights WITHOUT the "+1" (continuous coordinates).  torchvision / detectron2 are
+ * absent from the reference tree and from this image: restated from the published algorithm,
+ * PARITY UNPINNED. */
+static float ref_iou0(const float *a, const float *b)
+{
+    float left = a[0] > b[0] ? a[0] : b[0], right = a[2] < b[2] ? a[2] : b[2];
+    float top = a[1] > b[1] ? a[1] : b[1], bottom = a[3] < b[3] ? a[3] : b[3];
+    float width = right - left, height = bottom - top;
+    width = width > 0.f ? width : 0.f;
+    height = height > 0.f ? height : 0.f;
+    float interS = width * height;
+    float Sa = (a[2] - a[0]) * (a[3] - a[1]);
+    float Sb = (b[2] - b[0]) * (b[3] - b[1]);
+    return interS / (Sa + Sb - interS);
+}
+
+int ref_nms_sorted_plain(const float *boxes, int n, float thresh, int64_t *keep)
+{
+    int num = 0;
+    unsigned char *removed = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    for (int i = 0; i < n; ++i) {
+        if (removed[i])
+            continue;
+        keep[num++] = i;
+        for (int j = i + 1; j < n; ++j)
+            if (ref_iou0(boxes + 5 * i, boxes + 5 * j) > thresh)
+                removed[j] = 1;
+    }
+    free(removed);
+    return num;
+}
+
 int ref_nms_sorted(const float *boxes, int n, float thresh, int64_t *keep)
 {
     int num = 0;

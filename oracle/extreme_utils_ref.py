@@ -91,6 +91,23 @@ def nms(dets, scores, threshold):
     return torch.sort(order[keep[:num]])[0]
 
 
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms as detectron2.layers.batched_nms calls it (the reference's
+    ml_nms, core/layers/ml_nms.py:25): boxes of different classes are moved apart by
+    idxs * (max coordinate + 1), then plain NMS (IoU without "+1", strict >); returns the kept
+    indices in decreasing score order.  PARITY UNPINNED (torchvision absent)."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    off = idxs.to(boxes) * (boxes.max() + 1)
+    shifted = boxes.float() + off[:, None]
+    order = torch.sort(scores.float(), descending=True, stable=True)[1]
+    b = torch.cat([shifted, scores.float()[:, None]], 1)[order].contiguous()
+    keep = torch.zeros((b.size(0),), dtype=torch.int64)
+    lib().ref_nms_sorted_plain.restype = ctypes.c_int
+    num = lib().ref_nms_sorted_plain(_p(b), b.size(0), ctypes.c_float(float(iou_threshold)), _p(keep))
+    return order[keep[:num]]
+
+
 def uniform_upsample_fused(poly, p_num):
     """C restatement of RefineNet.uniform_upsample (snake_head.py:764-794) as one routine.
 

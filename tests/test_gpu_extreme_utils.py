@@ -180,3 +180,28 @@ def test_nms_known_answers(device):
     assert ext.nms(pair.to(device), sc[:2].to(device), 0.33).tolist() == [1]
     empty = ext.nms(torch.zeros((0, 4), device=device), torch.zeros((0,), device=device), 0.5)
     assert empty.numel() == 0 and not empty.is_cuda          # the reference's CPU-empty quirk
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 300, 1500])
+def test_ml_nms_against_the_oracle(device, n):
+    """dance_amd.ml_nms (the reference's core/layers/ml_nms.py:8-31 over detectron2's batched_nms)
+    against the C restatement of torchvision's NMS: kept indices identical, in score order."""
+    from _util import FakeBoxes, FakeInstances
+    from dance_amd import ml_nms
+    g = torch.Generator().manual_seed(n)
+    ctr = torch.rand((n, 2), generator=g) * 300
+    wh = torch.rand((n, 2), generator=g) * 80 + 4
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
+    scores = torch.rand((n,), generator=g)
+    classes = torch.randint(0, 3, (n,), generator=g)
+    for thr in (0.3, 0.6):
+        want = cref.batched_nms(boxes, scores, classes, thr)
+        got = ml_nms.batched_nms(boxes.to(device), scores.to(device), classes.to(device), thr)
+        assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+    inst = FakeInstances((400, 400), pred_boxes=FakeBoxes(boxes.to(device)), scores=scores.to(device),
+                         pred_classes=classes.to(device))
+    out = ml_nms.ml_nms(inst, 0.6, max_proposals=10)
+    want = cref.batched_nms(boxes, scores, classes, 0.6)[:10]
+    assert torch.equal(out.scores.cpu(), scores[want]) and torch.equal(out.pred_boxes.tensor.cpu(), boxes[want])
+    assert ml_nms.ml_nms(inst, 0.0) is inst
+    assert ml_nms.batched_nms(boxes[:0].to(device), scores[:0].to(device), classes[:0].to(device), 0.5).numel() == 0

@@ -208,3 +208,16 @@ def test_nms_oracle_known_answers():
     assert cref.nms(pair, sc[:2], 0.34).tolist() == [0, 1]       # IoU = 50 / 150
     assert cref.nms(pair, sc[:2], 0.33).tolist() == [1]
     assert cref.nms(torch.zeros((0, 4)), torch.zeros((0,)), 0.5).numel() == 0
+
+
+def test_batched_nms_oracle_known_answers():
+    """C restatement of torchvision's NMS (no "+1", strict >) behind detectron2.layers.batched_nms,
+    the call of the reference's ml_nms (core/layers/ml_nms.py:25).  PARITY UNPINNED: hand-computed."""
+    pair = torch.tensor([[0., 0., 10., 10.], [5., 0., 15., 10.]])               # IoU = 50 / 150
+    sc = torch.tensor([0.9, 0.8])
+    same = torch.zeros(2, dtype=torch.int64)
+    assert cref.batched_nms(pair, sc, same, 0.34).tolist() == [0, 1]
+    assert cref.batched_nms(pair, sc, same, 0.33).tolist() == [0]
+    assert cref.batched_nms(pair, sc, torch.tensor([0, 1]), 0.33).tolist() == [0, 1]   # other class: kept
+    assert cref.batched_nms(pair, torch.tensor([0.1, 0.8]), same, 0.33).tolist() == [1]  # score order
+    assert cref.batched_nms(torch.zeros((0, 4)), torch.zeros((0,)), torch.zeros((0,), dtype=torch.int64), 0.5).numel() == 0
