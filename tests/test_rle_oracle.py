@@ -94,3 +94,76 @@ def test_get_polygon_rles_shape():
     out = rle_ref.get_polygon_rles(polys, (30, 40))
     assert [o["size"] for o in out] == [[30, 40], [30, 40]]
     assert out[0]["counts"] == b"f9:d000000000000000000^b0" and isinstance(out[1]["counts"], bytes)
+
+
+def _parity_restatement(xy, h, w):
+    """The HIP kernel's formulation (csrc/raster.hip) in plain Python: every step of every edge is
+    examined on its own, a crossing toggles its position, runs are read off the positions left
+    with an odd count, and h*w always closes the last run.  Equal to the library's
+    sort-difference-fold on every input is what lets the kernel use a bitmap instead of a sort."""
+    import math
+    xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+    k = len(xy)
+    vx = [int(np.trunc(5.0 * x + .5)) for x in xy[:, 0]]
+    vy = [int(np.trunc(5.0 * y + .5)) for y in xy[:, 1]]
+    vx.append(vx[0])
+    vy.append(vy[0])
+    odd = set()
+    for e in range(k):
+        xs, xe, ys, ye = vx[e], vx[e + 1], vy[e], vy[e + 1]
+        dx, dy = abs(xe - xs), abs(ys - ye)
+        n = max(dx, dy)
+        if n == 0:
+            continue
+        xmajor = dx >= dy
+        back = (xmajor and xs > xe) or (not xmajor and ys > ye)
+        if back:
+            xs, xe, ys, ye = xe, xs, ye, ys
+        s = (ye - ys) / dx if xmajor else (xe - xs) / dy
+
+        def point(t):
+            if xmajor:
+                return t + xs, int(np.trunc(ys + s * t + .5))
+            return int(np.trunc(xs + s * t + .5)), t + ys
+
+        for d in range(1, n + 1):
+            up, vp = point(n - d + 1 if back else d - 1)
+            uc, vc = point(n - d if back else d)
+            if uc == up:
+                continue
+            xd = ((uc if uc < up else uc - 1) + .5) / 5.0 - .5
+            if math.floor(xd) != xd or xd < 0 or xd > w - 1:
+                continue
+            yd = math.ceil(min(max((min(vc, vp) + .5) / 5.0 - .5, 0), h))
+            p = int(xd) * h + int(yd)
+            if p < h * w:
+                odd ^= {p}
+    out, prev = [], 0
+    for p in sorted(odd):
+        out.append(p - prev)
+        prev = p
+    out.append(h * w - prev)
+    return np.array(out, dtype=np.uint32)
+
+
+def test_sort_and_fold_equals_position_parity():
+    rng = np.random.default_rng(0)
+    for it in range(60):
+        h, w = [(60, 80), (37, 53), (120, 90)][it % 3]
+        k = int(rng.integers(3, 24))
+        mode = it % 5
+        if mode == 0:
+            xy = rng.uniform(-20, max(h, w) + 20, (k, 2))
+        elif mode == 1:
+            xy = rng.integers(-5, max(h, w) + 5, (k, 2)).astype(float)          # vertices on pixel corners
+        elif mode == 2:
+            xy = rng.integers(-5, max(h, w) + 5, (k, 2)) + 0.5                  # ... on pixel centres
+        elif mode == 3:
+            xy = np.round(rng.uniform(0, w, (k, 2)) * 5) / 5 + 0.1              # 5x + .5 integral: rounding ties
+        else:
+            xy = rng.uniform(0, w, (k, 2))
+            xy = np.concatenate([xy, xy])                                       # traced twice: all pairs cancel
+        xy = xy.astype(np.float32).astype(np.float64)
+        assert np.array_equal(rle_ref.fr_poly(xy, h, w), _parity_restatement(xy, h, w)), (it, mode)
+    for c, (h, w) in (([[0, 0], [80, 0], [80, 60], [0, 60]], (60, 80)), ([[79, 0], [80, 0], [80, 60], [79, 60]], (60, 80))):
+        assert np.array_equal(rle_ref.fr_poly(c, h, w), _parity_restatement(c, h, w))
