@@ -28,10 +28,14 @@ with torch.no_grad():
     ms = timed(lambda: ops.bottom_out16(feats, 1, layers))
     print("HIP  bottom_out16 : %8.3f ms  %.0f TFLOP/s algorithmic (x3 = %.0f f16)" % (ms, flops / ms / 1e9, 3 * flops / ms / 1e9))
     def stock():
-        x = feats[:, 1:].contiguous(memory_format=torch.channels_last)
-        for conv in net.bottom_out:
-            x = conv(x)
-        return x.permute(0, 2, 3, 1).contiguous()
+        modules._ConvNormAct.use_hip = False                 # the plain torch.nn ops
+        try:
+            x = feats[:, 1:].contiguous(memory_format=torch.channels_last)
+            for conv in net.bottom_out:
+                x = conv(x)
+            return x.permute(0, 2, 3, 1).contiguous()
+        finally:
+            modules._ConvNormAct.use_hip = True
     ms2 = timed(stock, reps=3)
     print("torch.nn (MIOpen) : %8.3f ms  %.0f TFLOP/s   speed-up %.2fx" % (ms2, flops / ms2 / 1e9, ms2 / ms))
     a, c = ops.bottom_out16(feats, 1, layers), stock()
