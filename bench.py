@@ -377,6 +377,64 @@ def main():
             mask_rle["cpu_oracle"] = {"polygons_per_s": 200 / dt, "cores": 1, "kind": "port",
                                       "sample": "first 200 of the same contours, oracle/rle_ref.c through ctypes"}
 
+        # the producer of the boxes: FCOSE decode of the detector head's outputs,
+        # forward_for_single_feature_map of every level and image (fcose_outputs.py:444-521), before NMS
+        from dance_amd import fcose_outputs
+        fc_shapes, fc_strides, fc_c, fc_th = [(100, 152), (50, 76), (25, 38), (13, 19), (7, 10)], [8, 16, 32, 64, 128], 80, 0.05
+        gg = torch.Generator(device=dev).manual_seed(77)
+        fc_logits = [torch.randn(b, fc_c, hh, ww, generator=gg, device=dev) * 1.5 - 5.0 for hh, ww in fc_shapes]
+        fc_ctr = [torch.randn(b, 1, hh, ww, generator=gg, device=dev) for hh, ww in fc_shapes]
+        fc_reg = [torch.rand(b, 4, hh, ww, generator=gg, device=dev) * 6 + 0.25 for hh, ww in fc_shapes]
+        fc_ext = [torch.randn(b, 4, hh, ww, generator=gg, device=dev) * 0.3 for hh, ww in fc_shapes]
+        fc_loc = fcose_outputs.compute_locations(fc_logits, fc_strides)
+
+        def fc_hip():
+            return fcose_outputs.decode_candidates(fc_loc, fc_logits, fc_reg, fc_ext, fc_ctr, fc_strides, fc_th, True)
+
+        def fc_stock():
+            # the reference's op sequence with stock torch ops (per level: permute, sigmoid, mask;
+            # per image: nonzero, gathers, stack, sqrt)
+            n_out = 0
+            for l, (hh, ww) in enumerate(fc_shapes):
+                cls = fc_logits[l].permute(0, 2, 3, 1).reshape(b, -1, fc_c).sigmoid()
+                regl = (fc_reg[l] * fc_strides[l]).permute(0, 2, 3, 1).reshape(b, -1, 4)
+                extl = fc_ext[l].permute(0, 2, 3, 1).reshape(b, -1, 4)
+                cls = cls * fc_ctr[l].permute(0, 2, 3, 1).reshape(b, -1).sigmoid()[:, :, None]
+                cand = cls > fc_th
+                for i in range(b):
+                    nz = cand[i].nonzero()
+                    pl, r, e = fc_loc[l][nz[:, 0]], regl[i][nz[:, 0]], extl[i][nz[:, 0]]
+                    det = torch.stack([pl[:, 0] - r[:, 0], pl[:, 1] - r[:, 1], pl[:, 0] + r[:, 2], pl[:, 1] + r[:, 3]], 1)
+                    bw, bh = det[:, 2] - det[:, 0], det[:, 3] - det[:, 1]
+                    torch.stack([pl[:, 0] + bw * e[:, 0], det[:, 1], det[:, 0], pl[:, 1] + bh * e[:, 1],
+                                 pl[:, 0] + bw * e[:, 2], det[:, 3], det[:, 2], pl[:, 1] + bh * e[:, 3]], 1)
+                    torch.sqrt(cls[i][cand[i]])
+                    n_out += nz.size(0)
+            return n_out
+
+        def wall_ms(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r_ = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / reps, r_
+
+        fc_ms, (fc_fields, _) = wall_ms(fc_hip, 10)
+        fc_stock_ms, fc_n = wall_ms(fc_stock, 3)
+        fc_bytes = sum(b * (fc_c + 9) * hh * ww * 4 for hh, ww in fc_shapes)
+        fcose_fig = {"stage": "FCOSE decode of %d images x 5 levels (800x1216) x %d classes: sigmoid scores x centerness, "
+                              "threshold %.2f, compaction in `nonzero` order, box + extreme-point decode; outside the "
+                              "timed step" % (b, fc_c, fc_th),
+                     "kernel": "k_fcose_count + torch.cumsum + k_fcose_fill (5 + 5 launches)", "candidates": int(
+                         fc_fields["scores"].numel()), "ms_wall_incl_one_sync": fc_ms,
+                     "algorithmic_GBps": fc_bytes / fc_ms / 1e6, "stock_torch_ms": fc_stock_ms,
+                     "speedup_vs_stock": fc_stock_ms / fc_ms, "stock_candidates": fc_n,
+                     "note": "host-inclusive wall time (the decode ends in one device -> host copy of the segment "
+                             "bounds; the stock sequence syncs once per image and level in nonzero())"}
+        del fc_logits, fc_ctr, fc_reg, fc_ext, fc_fields
+
     if rank == 0:
         # per-stage device time from the HIP events recorded inside the timed steps
         stage_ms = [0.0] * len(STAGE_NAMES)
@@ -491,6 +549,7 @@ def main():
             "feat_prep": feat_prep,
             "mask_rle": mask_rle,
             "attender": attender_fig,
+            "fcose_decode": fcose_fig,
             "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,
                                  "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),
                                  "note": "reference scope `contour_sampling`, outside the timed step"},

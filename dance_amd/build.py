@@ -28,6 +28,7 @@ SOURCES = [
     ("featprep16.hip", []),
     ("raster.hip", ["-ffp-contract=off"]),
     ("attender.hip", []),
+    ("fcose.hip", ["-ffp-contract=off"]),
 ]
 HEADERS = ["common.h", "sampling.h", "p16.h", os.path.join("..", "..", "include", "dance_hip.h")]
 

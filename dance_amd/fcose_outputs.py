@@ -1,0 +1,172 @@
+"""FCOSE box decode: the producer of the boxes and extreme points the contour path starts from
+(SURVEY 8f row 3).  Inference half of the reference's `FCOSEOutputs`
+(core/modeling/fcose/fcose_outputs.py:125-173, 419-542), same constructor and method names:
+
+    FCOSEOutputs(images, locations, logits_pred, reg_pred, ext_pred, ctrness_pred, ...,
+                 thresh_with_ctr, gt_instances=None).predict_proposals() -> list[Instances]
+
+Fields of each result as the reference's: pred_boxes, scores, pred_classes, locations,
+ext_points (when ext_pred is given).  The threshold / `nonzero` / gather / decode of all levels
+and images runs in libdance_hip.so (csrc/fcose.hip: two passes over the logits and one prefix
+sum, one device -> host copy of the segment boundaries instead of the reference's two syncs per
+image and level); the per-level top-k is torch.topk on the level's slice, the multi-class NMS is
+dance_amd.ml_nms.  `losses()` (training) is out of scope and raises.
+"""
+import torch
+
+from . import ml_nms as _ml_nms
+from ._lib import check, current_stream, lib, ptr
+from .structures import Boxes, ExtremePoints, Instances
+
+
+def compute_locations(features, strides):
+    """FCOSE.compute_locations (core/modeling/fcose/fcose.py:118-142): per level the (h*w, 2)
+    image coordinates (x, y) of the feature map's cells, row-major."""
+    out = []
+    for f, s in zip(features, strides):
+        h, w = f.size()[-2:]
+        xs = torch.arange(0, w * s, step=s, dtype=torch.float32, device=f.device)
+        ys = torch.arange(0, h * s, step=s, dtype=torch.float32, device=f.device)
+        out.append(torch.stack((xs.repeat(h), ys.repeat_interleave(w)), dim=1) + s // 2)
+    return out
+
+
+def decode_candidates(locations, logits_pred, reg_pred, ext_pred, ctrness_pred, strides, pre_nms_thresh,
+                      thresh_with_ctr):
+    """All levels and images at once -> (fields, bounds): fields = dict of flat tensors over the
+    candidates in the reference's order (image, level, location, class): raw (score before the
+    square root), scores, classes, locations, boxes, ext (or None); bounds[i][l] .. bounds[i][l+1]
+    = slice of image i, level l (Python ints; bounds[i] has one entry per level plus the end)."""
+    dev = logits_pred[0].device
+    if not dev.type == "cuda":
+        raise RuntimeError("dance_amd.fcose_outputs needs GPU tensors (got a %s tensor)" % dev)
+    n, c = logits_pred[0].size(0), logits_pred[0].size(1)
+    hws = [int(x.size(2) * x.size(3)) for x in logits_pred]
+    lvl_off = [0]
+    for hw in hws:
+        lvl_off.append(lvl_off[-1] + hw)
+    total = lvl_off[-1]
+    cls = [x.float().contiguous() for x in logits_pred]
+    ctr = [x.float().contiguous() for x in ctrness_pred]
+    reg = [x.float().contiguous() for x in reg_pred]
+    ext = [x.float().contiguous() for x in ext_pred] if ext_pred is not None else None
+    locs = [x.float().contiguous() for x in locations]
+    for l, hw in enumerate(hws):
+        if cls[l].shape[:2] != (n, c) or ctr[l].numel() != n * hw or reg[l].numel() != n * 4 * hw \
+                or locs[l].shape != (hw, 2) or (ext is not None and ext[l].numel() != n * 4 * hw):
+            raise RuntimeError("fcose decode: level %d: logits (n,c,h,w), ctrness (n,1,h,w), reg / ext "
+                               "(n,4,h,w), locations (h*w,2) expected" % l)
+    counts = torch.empty((n, total), dtype=torch.int32, device=dev)
+    flag = 1 if thresh_with_ctr else 0
+    with torch.cuda.device(dev):
+        st = current_stream()
+        for l, hw in enumerate(hws):
+            check(lib().dance_fcose_count(ptr(cls[l]), ptr(ctr[l]), ptr(counts), total, lvl_off[l], n, c, hw,
+                                          float(pre_nms_thresh), flag, st), "fcose_count")
+        cum = torch.cumsum(counts.view(-1), 0, dtype=torch.int64)
+        # segment starts of every (image, level) and the grand total: the one host copy
+        idx = (torch.arange(n, device=dev)[:, None] * total + torch.tensor(lvl_off[:-1], device=dev)[None]).view(-1)
+        if n * total:
+            starts = (cum[idx] - counts.view(-1)[idx]).tolist() + [int(cum[-1])]
+        else:
+            starts = [0] * (n * len(hws) + 1)
+        m = starts[-1]
+        raw = torch.empty((m,), dtype=torch.float32, device=dev)
+        scores = torch.empty((m,), dtype=torch.float32, device=dev)
+        classes = torch.empty((m,), dtype=torch.int64, device=dev)
+        out_loc = torch.empty((m, 2), dtype=torch.float32, device=dev)
+        boxes = torch.empty((m, 4), dtype=torch.float32, device=dev)
+        extpts = torch.empty((m, 4, 2), dtype=torch.float32, device=dev) if ext is not None else None
+        if m:
+            for l, hw in enumerate(hws):
+                check(lib().dance_fcose_fill(ptr(cls[l]), ptr(ctr[l]), ptr(reg[l]),
+                                             ptr(ext[l]) if ext is not None else None, ptr(locs[l]),
+                                             ptr(counts), ptr(cum), total, lvl_off[l], n, c, hw,
+                                             float(strides[l]), float(pre_nms_thresh), flag, ptr(raw),
+                                             ptr(scores), ptr(classes), ptr(out_loc), ptr(boxes),
+                                             ptr(extpts) if extpts is not None else None, st), "fcose_fill")
+    nl = len(hws)
+    bounds = [starts[i * nl:(i + 1) * nl] + [starts[(i + 1) * nl]] for i in range(n)]
+    return dict(raw=raw, scores=scores, classes=classes, locations=out_loc, boxes=boxes, ext=extpts), bounds
+
+
+class FCOSEOutputs(object):
+    def __init__(self, images, locations, logits_pred, reg_pred, ext_pred, ctrness_pred, focal_loss_alpha,
+                 focal_loss_gamma, iou_loss, ext_loss, center_sample, sizes_of_interest, strides, radius,
+                 num_classes, pre_nms_thresh, pre_nms_top_n, nms_thresh, fpn_post_nms_top_n, thresh_with_ctr,
+                 gt_instances=None, instances_cls=Instances, boxes_cls=Boxes, ext_cls=ExtremePoints):
+        """fcose_outputs.py:126-173.  `images` needs `len()` and `.image_sizes`.  A Detectron2
+        deployment passes its own Instances / Boxes / ExtremePoints classes through the last
+        three arguments."""
+        self.logits_pred, self.reg_pred, self.ext_pred, self.ctrness_pred = logits_pred, reg_pred, ext_pred, ctrness_pred
+        self.locations = locations
+        self.gt_instances = gt_instances
+        self.num_feature_maps = len(logits_pred)
+        self.num_images = len(images)
+        self.image_sizes = images.image_sizes
+        self.focal_loss_alpha, self.focal_loss_gamma = focal_loss_alpha, focal_loss_gamma
+        self.iou_loss, self.ext_loss = iou_loss, ext_loss
+        self.center_sample, self.sizes_of_interest = center_sample, sizes_of_interest
+        self.strides, self.radius, self.num_classes = strides, radius, num_classes
+        self.pre_nms_thresh, self.pre_nms_top_n = pre_nms_thresh, pre_nms_top_n
+        self.nms_thresh, self.fpn_post_nms_top_n = nms_thresh, fpn_post_nms_top_n
+        self.thresh_with_ctr = thresh_with_ctr
+        self._instances, self._boxes, self._ext = instances_cls, boxes_cls, ext_cls
+
+    def losses(self):
+        raise NotImplementedError("dance_amd.FCOSEOutputs covers inference (predict_proposals); "
+                                  "training losses are outside the contour path's scope")
+
+    def _boxlists(self, fields, bounds, image_sizes):
+        """Per image and level the reference's result of forward_for_single_feature_map
+        (fcose_outputs.py:472-521), including its top-k when a level has more candidates than
+        pre_nms_top_n (492-499; `sorted=False`: the order among the kept is unspecified there)."""
+        out = []
+        for i, b in enumerate(bounds):
+            per_level = []
+            for l in range(len(b) - 1):
+                lo, hi = b[l], b[l + 1]
+                sel = slice(lo, hi)
+                if hi - lo > self.pre_nms_top_n:
+                    sel = torch.topk(fields["raw"][lo:hi], self.pre_nms_top_n, sorted=False)[1] + lo
+                box = self._boxes(fields["boxes"][sel])
+                inst = self._instances(image_sizes[i])
+                inst.pred_boxes = box
+                inst.scores = fields["scores"][sel]
+                inst.pred_classes = fields["classes"][sel]
+                inst.locations = fields["locations"][sel]
+                if fields["ext"] is not None:
+                    inst.ext_points = self._ext(fields["ext"][sel])
+                per_level.append(inst)
+            out.append(per_level)
+        return out
+
+    def forward_for_single_feature_map(self, locations, box_cls, reg_pred, ext_pred, ctrness, image_sizes):
+        """fcose_outputs.py:444-521 for one level; `reg_pred` already multiplied by the level's
+        stride as predict_proposals does (431)."""
+        fields, bounds = decode_candidates([locations], [box_cls], [reg_pred], None if ext_pred is None else [ext_pred],
+                                           [ctrness], [1.0], self.pre_nms_thresh, self.thresh_with_ctr)
+        return [per_level[0] for per_level in self._boxlists(fields, bounds, image_sizes)]
+
+    def predict_proposals(self):
+        """fcose_outputs.py:419-442."""
+        fields, bounds = decode_candidates(self.locations, self.logits_pred, self.reg_pred, self.ext_pred,
+                                           self.ctrness_pred, self.strides, self.pre_nms_thresh,
+                                           self.thresh_with_ctr)
+        boxlists = [self._instances.cat(per_level) for per_level in self._boxlists(fields, bounds, self.image_sizes)]
+        return self.select_over_all_levels(boxlists)
+
+    def select_over_all_levels(self, boxlists):
+        """fcose_outputs.py:523-542: multi-class NMS, then the fpn_post_nms_top_n best by score
+        (ties at the threshold all stay, as with the reference's `>=`)."""
+        results = []
+        for boxlist in boxlists:
+            result = _ml_nms.ml_nms(boxlist, self.nms_thresh)
+            number_of_detections = len(result)
+            if number_of_detections > self.fpn_post_nms_top_n > 0:
+                cls_scores = result.scores
+                image_thresh, _ = torch.kthvalue(cls_scores.cpu(), number_of_detections - self.fpn_post_nms_top_n + 1)
+                keep = torch.nonzero(cls_scores >= image_thresh.item()).squeeze(1)
+                result = result[keep]
+            results.append(result)
+        return results

@@ -84,3 +84,117 @@ class ExtremePoints(_PointSet):
 
     def __repr__(self):
         return "ExtPts(" + str(self.tensor) + ")"
+
+
+class Boxes:
+    """(N, 4) xyxy boxes: the part of detectron2.structures.Boxes the detector's decode and the
+    postprocessing touch (`tensor`, indexing, `clip`, `scale`, `nonempty`, `area`)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor.reshape(-1, 4) if tensor.numel() == 0 else tensor
+
+    def clip(self, box_size):
+        h, w = box_size
+        self.tensor[:, 0].clamp_(min=0, max=w)
+        self.tensor[:, 1].clamp_(min=0, max=h)
+        self.tensor[:, 2].clamp_(min=0, max=w)
+        self.tensor[:, 3].clamp_(min=0, max=h)
+
+    def scale(self, scale_x, scale_y):
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
+    def nonempty(self, threshold=0):
+        b = self.tensor
+        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+
+    def area(self):
+        b = self.tensor
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return Boxes(self.tensor[item].view(1, -1))
+        return Boxes(self.tensor[item])
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    def __repr__(self):
+        return "Boxes(" + str(self.tensor) + ")"
+
+
+class Instances:
+    """Per-image bag of equally long fields: the part of detectron2.structures.Instances the
+    detector's decode, `ml_nms` and the contour heads use (attribute fields, `has`,
+    `get_fields`, indexing, `len`, `cat`)."""
+
+    def __init__(self, image_size, **fields):
+        object.__setattr__(self, "_image_size", image_size)
+        object.__setattr__(self, "_fields", {})
+        for k, v in fields.items():
+            self.set(k, v)
+
+    @property
+    def image_size(self):
+        return self._image_size
+
+    def __setattr__(self, name, val):
+        if name.startswith("_"):
+            object.__setattr__(self, name, val)
+        else:
+            self.set(name, val)
+
+    def __getattr__(self, name):
+        if name == "_fields" or name not in self._fields:
+            raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
+        return self._fields[name]
+
+    def set(self, name, value):
+        for v in self._fields.values():
+            assert len(v) == len(value), "Adding a field of length {} to a Instances of length {}".format(
+                len(value), len(v))
+            break
+        self._fields[name] = value
+
+    def has(self, name):
+        return name in self._fields
+
+    def get(self, name):
+        return self._fields[name]
+
+    def get_fields(self):
+        return self._fields
+
+    def __getitem__(self, item):
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            ret.set(k, v[item])
+        return ret
+
+    def __len__(self):
+        for v in self._fields.values():
+            return len(v)
+        raise NotImplementedError("Empty Instances does not support __len__!")
+
+    @staticmethod
+    def cat(instance_lists):
+        assert len(instance_lists) > 0
+        if len(instance_lists) == 1:
+            return instance_lists[0]
+        ret = Instances(instance_lists[0].image_size)
+        for k in instance_lists[0]._fields.keys():
+            values = [i.get(k) for i in instance_lists]
+            v0 = values[0]
+            if isinstance(v0, torch.Tensor):
+                values = torch.cat(values, dim=0)
+            elif hasattr(type(v0), "cat"):
+                values = type(v0).cat(values)
+            else:
+                values = type(v0)(torch.cat([v.tensor for v in values], dim=0))
+            ret.set(k, values)
+        return ret

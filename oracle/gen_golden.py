@@ -434,6 +434,73 @@ def gen_edge_head():
           pred_polys=polys)
 
 
+FCOSE_LEVELS = (((12, 16), 8), ((6, 8), 16), ((3, 4), 32))
+FCOSE_CASES = (   # tag, seed, thresh, with_ctr, pre_top_n, nms_thresh, post_top_n, with_ext
+    ("plain", 151, 0.05, True, 1000, 0.6, 100, True),
+    ("topk", 62, 0.05, False, 20, 0.6, 10, True),
+    ("sparse", 63, 0.45, True, 1000, 0.5, 100, True),
+)
+
+
+def fcose_inputs(seed, n=2, c=4):
+    g = torch.Generator().manual_seed(seed)
+    logits, reg, ext, ctr = [], [], [], []
+    for (h, w), _ in FCOSE_LEVELS:
+        logits.append(torch.randn(n, c, h, w, generator=g) * 1.5 - 1.0)
+        reg.append(torch.rand(n, 4, h, w, generator=g) * 3.5 + 0.5)
+        ext.append(torch.randn(n, 4, h, w, generator=g) * 0.3)
+        ctr.append(torch.randn(n, 1, h, w, generator=g))
+    return logits, reg, ext, ctr
+
+
+def gen_fcose():
+    """The reference's own FCOSEOutputs.predict_proposals (fcose_outputs.py:419-542) on small
+    seeded head outputs: three levels, two images, four classes; with and without the per-level
+    top-k, the post-NMS cut and the extreme-point branch.  Inputs are stored in the fixture."""
+    from types import SimpleNamespace as NS
+    from oracle import fcose_ref
+    fo = ref_loader.load_fcose_outputs()
+    strides = [s for _, s in FCOSE_LEVELS]
+    locations = fcose_ref.compute_locations([hw for hw, _ in FCOSE_LEVELS], strides)
+    sizes = [(96, 128), (90, 120)]
+    out = {}
+    for tag, seed, th, with_ctr, pre, nms_th, post, with_ext in FCOSE_CASES:
+        logits, reg, ext, ctr = fcose_inputs(seed)
+        # no score within 1e-4 of the threshold: the candidate set must not depend on the last
+        # bits of exp()
+        for l in range(len(logits)):
+            s = torch.sigmoid(logits[l])
+            v = s * torch.sigmoid(ctr[l]) if with_ctr else s
+            assert float((v - th).abs().min()) > 1e-4, tag
+        images = type("Images", (), {"__len__": lambda self: len(sizes), "image_sizes": sizes})()
+        # torch 2.10 keeps the permuted strides through sigmoid(), and the reference's
+        # `candidate_inds.view(N, -1)` (fcose_outputs.py:466) then refuses an NCHW-contiguous
+        # input (torch 1.4 returned a contiguous tensor there); the same values in channels-last
+        # memory go through unchanged
+        cl = [x.contiguous(memory_format=torch.channels_last) for x in logits]
+        o = fo.FCOSEOutputs(images, locations, cl, reg, ext if with_ext else None, ctr, 0.25, 2.0, None, None,
+                            True, None, strides, 1.5, 4, th, pre, nms_th, post, with_ctr)
+        ref = o.predict_proposals()
+        mine = fcose_ref.predict_proposals(locations, logits, reg, ext if with_ext else None, ctr, strides, th,
+                                           with_ctr, pre, nms_th, post)
+        for l in range(len(logits)):
+            out["%s_logits%d" % (tag, l)], out["%s_reg%d" % (tag, l)] = logits[l], reg[l]
+            out["%s_ext%d" % (tag, l)], out["%s_ctr%d" % (tag, l)] = ext[l], ctr[l]
+        for i, (r, m) in enumerate(zip(ref, mine)):
+            got = dict(boxes=r.pred_boxes.tensor, scores=r.scores, classes=r.pred_classes, locations=r.locations)
+            if with_ext:
+                got["ext"] = r.ext_points.tensor
+            print("  fcose %-7s image %d: %d detections" % (tag, i, len(r.scores)))
+            for k, v in got.items():
+                assert v.shape == m[k].shape, (tag, i, k, v.shape, m[k].shape)
+                if v.dtype == torch.int64:
+                    assert torch.equal(v, m[k]), (tag, i, k)
+                else:
+                    _close(m[k], v, 1e-6, "fcose %s %s" % (tag, k))
+                out["%s_im%d_%s" % (tag, i, k)] = v
+    _save("g11_fcose", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -444,7 +511,7 @@ def main():
              "blocks": lambda: gen_blocks(sh), "snakenet": lambda: gen_snakenet(sh),
              "dance": lambda: gen_dance(sh), "dsnake": lambda: gen_dsnake(dh),
              "upsample2x": lambda: gen_upsample2x(sh), "bottom_out": lambda: gen_bottom_out(sh),
-             "attender": gen_attender, "edge_head": gen_edge_head}
+             "attender": gen_attender, "edge_head": gen_edge_head, "fcose": gen_fcose}
     # `python -m oracle.gen_golden attender ...` regenerates only the named fixtures (floating-
     # point fixtures move in the last bits with the host CPU's kernels: keep the committed ones)
     for name in (sys.argv[1:] or list(steps)):

@@ -227,3 +227,78 @@ def edge_head_cfg(**snake_over):
     cfg.MODEL.SNAKE_HEAD.EDGE_IN_TH = -1.0
     cfg.TEST = NS(GT_IN=NS(ON=False, WHAT=("instance",)))
     return cfg
+
+
+class _Instances:
+    """Placeholder for detectron2.structures.Instances as the detector's decode uses it:
+    attribute fields, indexing, len, cat (fcose_outputs.py:439, 508-519; ml_nms.py:22-28)."""
+
+    def __init__(self, image_size, **fields):
+        object.__setattr__(self, "image_size", image_size)
+        object.__setattr__(self, "_f", {})
+        for k, v in fields.items():
+            setattr(self, k, v)
+
+    def __setattr__(self, k, v):
+        self._f[k] = v
+
+    def __getattr__(self, k):
+        f = object.__getattribute__(self, "_f")
+        if k not in f:
+            raise AttributeError(k)
+        return f[k]
+
+    def has(self, name):
+        return name in self._f
+
+    def __len__(self):
+        return len(next(iter(self._f.values())))
+
+    def __getitem__(self, item):
+        return _Instances(self.image_size, **{k: v[item] for k, v in self._f.items()})
+
+    @staticmethod
+    def cat(lst):
+        out = _Instances(lst[0].image_size)
+        for k, v0 in lst[0]._f.items():
+            vals = [x._f[k] for x in lst]
+            setattr(out, k, torch.cat(vals, 0) if isinstance(v0, torch.Tensor)
+                    else type(v0)(torch.cat([v.tensor for v in vals], 0)))
+        return out
+
+
+class _Boxes(FakeBoxes):
+    def __getitem__(self, item):
+        return _Boxes(self.tensor[item])
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+
+def load_fcose_outputs():
+    """The reference's core/modeling/fcose/fcose_outputs.py (FCOSEOutputs) with its own
+    core/structures/pointset.py and core/layers/ml_nms.py.  detectron2.layers.batched_nms
+    (torchvision's, absent) is the restatement in oracle/extreme_utils_ref.py: the NMS step is
+    unpinned, the decode in front of it is the reference's own code."""
+    if "fcose" in _loaded:
+        return _loaded["fcose"]
+    load_reference()
+    _module("detectron2.structures", Instances=_Instances, Boxes=_Boxes)
+    _module("detectron2.utils")
+    _module("detectron2.utils.comm", get_world_size=lambda: 1)
+    sys.modules["fvcore.nn"].sigmoid_focal_loss_jit = None
+    _module("core.utils.comm", reduce_sum=lambda t: t)
+    sys.modules["detectron2.layers"].batched_nms = extreme_utils_ref.batched_nms
+    mlnms = _load("_dance_ref_ml_nms", REF + "/core/layers/ml_nms.py")
+    sys.modules["core.layers"].ml_nms = mlnms.ml_nms
+    pointset = _load("_dance_ref_pointset", REF + "/core/structures/pointset.py")
+    saved = sys.modules["core.structures"]
+    _module("core.structures", ExtremePoints=pointset.ExtremePoints, PolygonPoints=pointset.PolygonPoints)
+    pkg = _module("_dance_ref_fcose_pkg")
+    pkg.__path__ = []
+    _module("_dance_ref_fcose_pkg.utils", get_extreme_points=None)
+    try:
+        _loaded["fcose"] = _load("_dance_ref_fcose_pkg.fcose_outputs", REF + "/core/modeling/fcose/fcose_outputs.py")
+    finally:
+        sys.modules["core.structures"] = saved
+    return _loaded["fcose"]

@@ -123,3 +123,33 @@ def test_edge_head_refuses_unbuilt_options():
     keys = list(head.state_dict())
     assert keys[0] == "attender.0.weight" and "p5.4.norm.bias" in keys and "predictor.1.bias" in keys
     assert keys.index("p2.0.weight") < keys.index("predictor.0.weight") < keys.index("refine_head.bottom_out.0.weight")
+
+
+def test_fcose_locations_and_structures():
+    """compute_locations equals the restatement of fcose.py:129-142; Instances / Boxes behave as
+    the detector's decode and ml_nms need (fields, indexing, len, cat); CPU tensors are refused."""
+    import pytest
+    from dance_amd import fcose_outputs
+    from dance_amd.structures import Boxes, ExtremePoints, Instances
+    from oracle import fcose_ref
+    shapes, strides = [(5, 7), (3, 4), (1, 1)], [8, 16, 32]
+    feats = [torch.zeros(2, 3, h, w) for h, w in shapes]
+    for a, b in zip(fcose_outputs.compute_locations(feats, strides), fcose_ref.compute_locations(shapes, strides)):
+        assert torch.equal(a, b)
+    a = Instances((10, 20), pred_boxes=Boxes(torch.arange(8.0).view(2, 4)), scores=torch.tensor([0.5, 0.25]),
+                  ext_points=ExtremePoints(torch.zeros(2, 4, 2)))
+    b = Instances((10, 20), pred_boxes=Boxes(torch.zeros(0, 4)), scores=torch.zeros(0),
+                  ext_points=ExtremePoints(torch.zeros(0, 4, 2)))
+    c = Instances.cat([a, b, a])
+    assert len(c) == 4 and c.image_size == (10, 20) and c.has("scores") and not c.has("pred_classes")
+    assert isinstance(c.pred_boxes, Boxes) and isinstance(c.ext_points, ExtremePoints)
+    d = c[torch.tensor([3, 0])]
+    assert torch.equal(d.scores, torch.tensor([0.25, 0.5])) and len(d.pred_boxes) == 2
+    assert torch.equal(c.pred_boxes.area(), torch.tensor([4.0, 4.0, 4.0, 4.0]))
+    with pytest.raises(AssertionError):
+        a.pred_classes = torch.zeros(3)
+    with pytest.raises(AttributeError):
+        a.missing
+    with pytest.raises(RuntimeError):
+        fcose_outputs.decode_candidates([torch.zeros(4, 2)], [torch.zeros(1, 2, 2, 2)], [torch.zeros(1, 4, 2, 2)],
+                                        None, [torch.zeros(1, 1, 2, 2)], [8], 0.05, True)

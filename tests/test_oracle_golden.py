@@ -1,5 +1,6 @@
 """CPU: the oracle (C restatement + torch restatement) against the golden vectors that
 oracle/gen_golden.py produced with the reference's own code."""
+import pytest
 import torch
 
 from _util import CHAIN_TOL_WHITE, dance_state_dict, dsnake_state_dict, golden, rel_err
@@ -221,3 +222,31 @@ def test_batched_nms_oracle_known_answers():
     assert cref.batched_nms(pair, sc, torch.tensor([0, 1]), 0.33).tolist() == [0, 1]   # other class: kept
     assert cref.batched_nms(pair, torch.tensor([0.1, 0.8]), same, 0.33).tolist() == [1]  # score order
     assert cref.batched_nms(torch.zeros((0, 4)), torch.zeros((0,)), torch.zeros((0,), dtype=torch.int64), 0.5).numel() == 0
+
+
+FCOSE_LEVELS = (((12, 16), 8), ((6, 8), 16), ((3, 4), 32))
+FCOSE_CASES = (("plain", 0.05, True, 1000, 0.6, 100), ("topk", 0.05, False, 20, 0.6, 10),
+               ("sparse", 0.45, True, 1000, 0.5, 100))
+
+
+@pytest.mark.parametrize("case", FCOSE_CASES, ids=[c[0] for c in FCOSE_CASES])
+def test_fcose_restatement(case):
+    """oracle/fcose_ref.py against the reference's own FCOSEOutputs.predict_proposals
+    (fcose_outputs.py:419-542; fixture g11, inputs stored in it): classes bit-exact, boxes /
+    locations / extreme points bit-exact, scores 1e-6."""
+    from oracle import fcose_ref
+    tag, th, with_ctr, pre, nms_th, post = case
+    g = golden("g11_fcose")
+    t = lambda k: g[k]
+    strides = [s for _, s in FCOSE_LEVELS]
+    locations = fcose_ref.compute_locations([hw for hw, _ in FCOSE_LEVELS], strides)
+    got = fcose_ref.predict_proposals(locations, [t("%s_logits%d" % (tag, l)) for l in range(3)],
+                                      [t("%s_reg%d" % (tag, l)) for l in range(3)],
+                                      [t("%s_ext%d" % (tag, l)) for l in range(3)],
+                                      [t("%s_ctr%d" % (tag, l)) for l in range(3)], strides, th, with_ctr, pre,
+                                      nms_th, post)
+    for i, d in enumerate(got):
+        for k in ("classes", "boxes", "locations", "ext"):
+            assert torch.equal(d[k], t("%s_im%d_%s" % (tag, i, k))), (tag, i, k)
+        w = t("%s_im%d_scores" % (tag, i))
+        assert float(((d["scores"] - w).abs() / w).max()) <= 1e-6
