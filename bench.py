@@ -382,7 +382,7 @@ def main():
         from dance_amd import fcose_outputs
         fc_shapes, fc_strides, fc_c, fc_th = [(100, 152), (50, 76), (25, 38), (13, 19), (7, 10)], [8, 16, 32, 64, 128], 80, 0.05
         gg = torch.Generator(device=dev).manual_seed(77)
-        fc_logits = [torch.randn(b, fc_c, hh, ww, generator=gg, device=dev) * 1.5 - 5.0 for hh, ww in fc_shapes]
+        fc_logits = [torch.randn(b, fc_c, hh, ww, generator=gg, device=dev) * 1.5 - 6.5 for hh, ww in fc_shapes]
         fc_ctr = [torch.randn(b, 1, hh, ww, generator=gg, device=dev) for hh, ww in fc_shapes]
         fc_reg = [torch.rand(b, 4, hh, ww, generator=gg, device=dev) * 6 + 0.25 for hh, ww in fc_shapes]
         fc_ext = [torch.randn(b, 4, hh, ww, generator=gg, device=dev) * 0.3 for hh, ww in fc_shapes]

@@ -52,6 +52,13 @@ class SnakeNet16Struct(ctypes.Structure):
     ]
 
 
+class FcoseLevelStruct(ctypes.Structure):
+    """Mirror of `dance_fcose_level` (include/dance_hip.h)."""
+
+    _fields_ = [("cls", c_void_p), ("ctr", c_void_p), ("reg", c_void_p), ("ext", c_void_p),
+                ("locations", c_void_p), ("hw", c_int), ("stride", c_float)]
+
+
 P = c_void_p
 # name -> (restype, argtypes); every symbol include/dance_hip.h declares
 SIGNATURES = {
@@ -73,9 +80,8 @@ SIGNATURES = {
     "dance_polygon_rle": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P]),
     "dance_rle_to_string": (c_int, [P, P, c_int, c_int, P, P, c_int64, P, P]),
     "dance_rle_decode": (c_int, [P, P, c_int, c_int, P, c_int, c_int, P]),
-    "dance_fcose_count": (c_int, [P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, P]),
-    "dance_fcose_fill": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
-                                 c_float, c_int, P, P, P, P, P, P, P]),
+    "dance_fcose_count": (c_int, [P, c_int, P, c_int, c_int, c_float, c_int, P]),
+    "dance_fcose_fill": (c_int, [P, c_int, P, P, c_int, c_int, c_float, c_int, P, P, P, P, P, P, P]),
     "dance_uniform_upsample": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P]),
     "dance_nchw_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_gather_features": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,

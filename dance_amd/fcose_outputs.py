@@ -7,15 +7,15 @@
 
 Fields of each result as the reference's: pred_boxes, scores, pred_classes, locations,
 ext_points (when ext_pred is given).  The threshold / `nonzero` / gather / decode of all levels
-and images runs in libdance_hip.so (csrc/fcose.hip: two passes over the logits and one prefix
-sum, one device -> host copy of the segment boundaries instead of the reference's two syncs per
+and images runs in libdance_hip.so (csrc/fcose.hip: two launches over all levels' logits and one
+prefix sum, one device -> host copy of the segment boundaries instead of the reference's two syncs per
 image and level); the per-level top-k is torch.topk on the level's slice, the multi-class NMS is
 dance_amd.ml_nms.  `losses()` (training) is out of scope and raises.
 """
 import torch
 
 from . import ml_nms as _ml_nms
-from ._lib import check, current_stream, lib, ptr
+from ._lib import FcoseLevelStruct, check, current_stream, lib, ptr
 from .structures import Boxes, ExtremePoints, Instances
 
 
@@ -56,13 +56,17 @@ def decode_candidates(locations, logits_pred, reg_pred, ext_pred, ctrness_pred, 
                 or locs[l].shape != (hw, 2) or (ext is not None and ext[l].numel() != n * 4 * hw):
             raise RuntimeError("fcose decode: level %d: logits (n,c,h,w), ctrness (n,1,h,w), reg / ext "
                                "(n,4,h,w), locations (h*w,2) expected" % l)
+    if len(hws) > 8:
+        raise RuntimeError("fcose decode: at most 8 levels (DANCE_FCOSE_MAX_LEVELS)")
     counts = torch.empty((n, total), dtype=torch.int32, device=dev)
     flag = 1 if thresh_with_ctr else 0
+    table = (FcoseLevelStruct * len(hws))()
+    for l, hw in enumerate(hws):
+        table[l] = FcoseLevelStruct(ptr(cls[l]), ptr(ctr[l]), ptr(reg[l]), ptr(ext[l]) if ext is not None else None,
+                                    ptr(locs[l]), hw, float(strides[l]))
     with torch.cuda.device(dev):
         st = current_stream()
-        for l, hw in enumerate(hws):
-            check(lib().dance_fcose_count(ptr(cls[l]), ptr(ctr[l]), ptr(counts), total, lvl_off[l], n, c, hw,
-                                          float(pre_nms_thresh), flag, st), "fcose_count")
+        check(lib().dance_fcose_count(table, len(hws), ptr(counts), n, c, float(pre_nms_thresh), flag, st), "fcose_count")
         cum = torch.cumsum(counts.view(-1), 0, dtype=torch.int64)
         # segment starts of every (image, level) and the grand total: the one host copy
         idx = (torch.arange(n, device=dev)[:, None] * total + torch.tensor(lvl_off[:-1], device=dev)[None]).view(-1)
@@ -78,13 +82,9 @@ def decode_candidates(locations, logits_pred, reg_pred, ext_pred, ctrness_pred, 
         boxes = torch.empty((m, 4), dtype=torch.float32, device=dev)
         extpts = torch.empty((m, 4, 2), dtype=torch.float32, device=dev) if ext is not None else None
         if m:
-            for l, hw in enumerate(hws):
-                check(lib().dance_fcose_fill(ptr(cls[l]), ptr(ctr[l]), ptr(reg[l]),
-                                             ptr(ext[l]) if ext is not None else None, ptr(locs[l]),
-                                             ptr(counts), ptr(cum), total, lvl_off[l], n, c, hw,
-                                             float(strides[l]), float(pre_nms_thresh), flag, ptr(raw),
-                                             ptr(scores), ptr(classes), ptr(out_loc), ptr(boxes),
-                                             ptr(extpts) if extpts is not None else None, st), "fcose_fill")
+            check(lib().dance_fcose_fill(table, len(hws), ptr(counts), ptr(cum), n, c, float(pre_nms_thresh), flag,
+                                         ptr(raw), ptr(scores), ptr(classes), ptr(out_loc), ptr(boxes),
+                                         ptr(extpts) if extpts is not None else None, st), "fcose_fill")
     nl = len(hws)
     bounds = [starts[i * nl:(i + 1) * nl] + [starts[(i + 1) * nl]] for i in range(n)]
     return dict(raw=raw, scores=scores, classes=classes, locations=out_loc, boxes=boxes, ext=extpts), bounds

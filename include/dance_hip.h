@@ -148,31 +148,37 @@ int dance_rle_decode(const uint32_t *counts, const int32_t *m, int n, int cap, u
 
 /* ------------------------------------------- FCOSE box decode ------ */
 /* reference: FCOSEOutputs.forward_for_single_feature_map, core/modeling/fcose/
- * fcose_outputs.py:444-521, one FPN level per call (predict_proposals, 419-442, multiplies the
+ * fcose_outputs.py:444-521, for every FPN level (predict_proposals, 419-442, multiplies each
  * level's reg_pred by its stride: 431).  Two passes over the level's logits, in the reference's
  * own NCHW layout: cls (n,c,h,w), ctr (n,1,h,w), reg / ext (n,4,h,w) f32, hw = h*w.
  *
- * dance_fcose_count: counts[img * counts_stride + lvl_off + loc] (i32) = number of classes of
- *   that location whose score passes: sigmoid(cls) * sigmoid(ctr) > thresh when thresh_with_ctr,
- *   else sigmoid(cls) > thresh (463-465).  One counts row per image holds all levels
- *   (counts_stride = sum of the levels' hw, lvl_off = this level's start).
+ * All levels go in one launch: the caller lists them (host array of dance_fcose_level).
+ *
+ * dance_fcose_count: counts (n, total) i32, total = sum of the levels' hw; entry
+ *   [img][level start + loc] = number of classes of that location whose score passes:
+ *   sigmoid(cls) * sigmoid(ctr) > thresh when thresh_with_ctr, else sigmoid(cls) > thresh
+ *   (463-465).  reg / ext / locations / stride of the levels are not read.
  * dance_fcose_fill: cum = inclusive prefix sum (i64) of the whole counts array; candidate j of a
  *   location lands in slot cum - count + j, i.e. in the order of the reference's `nonzero()`
  *   (image, level, location, class).  Per candidate: raw = sigmoid(cls) * sigmoid(ctr),
  *   scores = sqrt(raw) (511), classes i64 (512), out_loc (.,2) = locations[loc] (513), boxes
  *   (.,4) = loc -+ reg * stride (501-506, bit-identical: separate fp32 multiply and add), extpts
- *   (.,4,2) = ExtremePoints.from_boxes (core/structures/pointset.py:110-130); ext and extpts may
- *   be NULL.  locations (hw,2) f32 as FCOSE.compute_locations gives them (fcose.py:129-142).
- *   The per-level top-k (492-499) and select_over_all_levels (523-542) stay with the caller
- *   (dance_amd/fcose_outputs.py: torch.topk, dance_nms_sorted_plain, kthvalue). */
-int dance_fcose_count(const float *cls, const float *ctr, int32_t *counts, int64_t counts_stride,
-                      int64_t lvl_off, int n, int c, int hw, float thresh, int thresh_with_ctr,
-                      void *stream);
-int dance_fcose_fill(const float *cls, const float *ctr, const float *reg, const float *ext,
-                     const float *locations, const int32_t *counts, const int64_t *cum,
-                     int64_t counts_stride, int64_t lvl_off, int n, int c, int hw, float stride,
-                     float thresh, int thresh_with_ctr, float *raw, float *scores, int64_t *classes,
-                     float *out_loc, float *boxes, float *extpts, void *stream);
+ *   (.,4,2) = ExtremePoints.from_boxes (core/structures/pointset.py:110-130); ext (all levels or
+ *   none) and extpts may be NULL.  locations (hw,2) f32 as FCOSE.compute_locations gives them
+ *   (fcose.py:129-142).  The per-level top-k (492-499) and select_over_all_levels (523-542) stay
+ *   with the caller (dance_amd/fcose_outputs.py: torch.topk, dance_nms_sorted_plain, kthvalue). */
+#define DANCE_FCOSE_MAX_LEVELS 8
+typedef struct dance_fcose_level {
+    const float *cls, *ctr, *reg, *ext, *locations;   /* device pointers, see above */
+    int hw;                                           /* h * w of the level */
+    float stride;                                     /* FPN stride: reg is multiplied by it */
+} dance_fcose_level;
+int dance_fcose_count(const dance_fcose_level *levels, int n_levels, int32_t *counts, int n, int c,
+                      float thresh, int thresh_with_ctr, void *stream);
+int dance_fcose_fill(const dance_fcose_level *levels, int n_levels, const int32_t *counts,
+                     const int64_t *cum, int n, int c, float thresh, int thresh_with_ctr, float *raw,
+                     float *scores, int64_t *classes, float *out_loc, float *boxes, float *extpts,
+                     void *stream);
 
 /* ------------------------------------------------- contour initialisation (a11-a15) - */
 enum {
