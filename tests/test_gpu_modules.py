@@ -148,3 +148,44 @@ def test_snake_fpn_head_is_the_dsnake_caller(device):
     assert [k for k in head.state_dict()][0].startswith("refine_head.")
     with pytest.raises(NotImplementedError):
         head.train()({"p2": None}, None, None)
+
+
+def test_detector_decode_to_contours_to_masks(device):
+    """The three widened steps compose: FCOSE head outputs -> FCOSEOutputs.predict_proposals
+    (dance_amd Instances) -> RefineNet.forward -> get_polygon_rles.  The contours equal those
+    of the same boxes handed over in the duck-typed test instances, bit for bit."""
+    from dance_amd import rle
+    from dance_amd.fcose_outputs import FCOSEOutputs, compute_locations
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("smooth_batched_box_v196")
+    cfg.vis_path = True                                   # the batched branch of forward()
+    net = _module(cfg, sd, device)
+    b, hf, wf = feats.size(0), feats.size(2), feats.size(3)
+    gen = torch.Generator().manual_seed(21)
+    shapes, strides = [(hf // 2, wf // 2), (hf // 4, wf // 4)], [8, 16]
+    logits = [(torch.randn(b, 3, h, w, generator=gen) * 1.5 - 3.0).to(device) for h, w in shapes]
+    ctr = [torch.randn(b, 1, h, w, generator=gen).to(device) for h, w in shapes]
+    reg = [(torch.rand(b, 4, h, w, generator=gen) * 3 + 1).to(device) for h, w in shapes]
+    ext = [(torch.rand(b, 4, h, w, generator=gen) - 0.5).to(device) for h, w in shapes]
+
+    class Images:
+        image_sizes = list(sizes)
+
+        def __len__(self):
+            return b
+
+    out = FCOSEOutputs(Images(), compute_locations(logits, strides), logits, reg, ext, ctr, 0.25, 2.0, None, None,
+                       True, None, strides, 1.5, 3, 0.05, 1000, 0.6, 6, True)
+    insts = out.predict_proposals()
+    assert [len(i) for i in insts] == [6] * b
+    plain = [FakeInstances(sizes[i], pred_boxes=FakeBoxes(insts[i].pred_boxes.tensor.clone())) for i in range(b)]
+    with torch.no_grad():
+        res, _ = net(feats.to(device), insts, None)
+        want, _ = net(feats.to(device), plain, None)
+    for r, w, size in zip(res, want, sizes):
+        assert r.pred_polys.tensor.shape == (6, 196, 2)
+        assert torch.equal(r.pred_polys.tensor, w.pred_polys.tensor)
+        assert r.has("ext_points") and r.has("scores")
+        polys = r.pred_polys.tensor.clone()
+        ok = torch.isfinite(polys).all(-1).all(-1)
+        masks = rle.get_polygon_rles(polys[ok].reshape(int(ok.sum()), -1), tuple(size))
+        assert len(masks) == int(ok.sum()) and all(m["size"] == list(size) for m in masks)
