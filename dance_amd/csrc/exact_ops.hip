@@ -17,7 +17,7 @@ char *error_buffer() { return g_error; }
 using dance::ceil_div;
 using dance::launch_check;
 
-extern "C" int dance_abi_version(void) { return 4; }
+extern "C" int dance_abi_version(void) { return 5; }
 extern "C" const char *dance_last_error(void) { return dance::error_buffer(); }
 
 extern "C" int dance_device_info(int *cu_count_host, int *lds_bytes_host)
@@ -327,13 +327,12 @@ __device__ __forceinline__ float nms_iou(const float *a, const float *b)
     return interS / (Sa + Sb - interS);
 }
 
-// grid (col_blocks, col_blocks), 64 threads; mask[i][col] bit j = IoU(box i, box 64 col + j) > thresh
-// for j later than i in the sorted order (nms.cu:23-67)
+// mask[i][col] bit j = IoU(box i, box 64 col + j) > thresh for j later than i in the sorted
+// order (nms.cu:23-67); one 64 x 64 tile of the pairs per workgroup of 64 threads
 template <int ONE>
-__global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float *__restrict__ boxes,
-                                                 unsigned long long *__restrict__ mask)
+__device__ __forceinline__ void nms_mask_tile(int n, int col_blocks, int row_start, int col_start, float thresh,
+                                              const float *__restrict__ boxes, unsigned long long *__restrict__ mask)
 {
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
     const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
     __shared__ float bb[64 * 5];
     if ((int)threadIdx.x < col_size)
@@ -348,14 +347,37 @@ __global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const floa
         for (int i = start; i < col_size; ++i)
             if (nms_iou<ONE>(cb, bb + i * 5) > thresh)
                 t |= 1ULL << i;
-        mask[(long long)cur * gridDim.x + col_start] = t;
+        mask[(long long)cur * col_blocks + col_start] = t;
     }
+}
+
+// grid (col_blocks, col_blocks)
+template <int ONE>
+__global__ __launch_bounds__(64) void k_nms_mask(int n, float thresh, const float *__restrict__ boxes,
+                                                 unsigned long long *__restrict__ mask)
+{
+    nms_mask_tile<ONE>(n, gridDim.x, blockIdx.y, blockIdx.x, thresh, boxes, mask);
+}
+
+// Segmented form: grid (max col_blocks, max col_blocks, segments); seg (segments, 3) i64 = first
+// box, number of boxes, first mask word of each segment (every segment an independent NMS)
+template <int ONE>
+__global__ __launch_bounds__(64) void k_nms_mask_seg(const long long *__restrict__ seg, float thresh,
+                                                     const float *__restrict__ boxes,
+                                                     unsigned long long *__restrict__ mask)
+{
+    const long long first = seg[3 * blockIdx.z];
+    const int n = (int)seg[3 * blockIdx.z + 1];
+    const int cb = (n + 63) / 64;
+    if ((int)blockIdx.x >= cb || (int)blockIdx.y >= cb)
+        return;
+    nms_mask_tile<ONE>(n, cb, blockIdx.y, blockIdx.x, thresh, boxes + 5 * first, mask + seg[3 * blockIdx.z + 2]);
 }
 
 // one wavefront: blocks of 64 boxes in order.  Inside a block the 64 decisions are serial but
 // touch only the block's diagonal mask words (one per lane); the kept rows are then OR-ed
 // into the removal words of the later blocks, lanes across the columns (nms.cu:105-121).
-__global__ __launch_bounds__(64) void k_nms_sweep(int n, int col_blocks, const unsigned long long *__restrict__ mask,
+__device__ __forceinline__ void nms_sweep_body(int n, int col_blocks, const unsigned long long *__restrict__ mask,
                                                   unsigned long long *__restrict__ remv, long long *__restrict__ keep,
                                                   int *__restrict__ count)
 {
@@ -391,6 +413,30 @@ __global__ __launch_bounds__(64) void k_nms_sweep(int n, int col_blocks, const u
         *count = num;
 }
 
+__global__ __launch_bounds__(64) void k_nms_sweep(int n, int col_blocks, const unsigned long long *__restrict__ mask,
+                                                  unsigned long long *__restrict__ remv, long long *__restrict__ keep,
+                                                  int *__restrict__ count)
+{
+    nms_sweep_body(n, col_blocks, mask, remv, keep, count);
+}
+
+// one workgroup (one wavefront) per segment; keep positions are relative to the segment
+__global__ __launch_bounds__(64) void k_nms_sweep_seg(const long long *__restrict__ seg,
+                                                      unsigned long long *__restrict__ mask,
+                                                      long long *__restrict__ keep, int *__restrict__ count)
+{
+    const long long first = seg[3 * blockIdx.x];
+    const int n = (int)seg[3 * blockIdx.x + 1];
+    const int cb = (n + 63) / 64;
+    unsigned long long *m = mask + seg[3 * blockIdx.x + 2];
+    if (n == 0) {
+        if (threadIdx.x == 0)
+            count[blockIdx.x] = 0;
+        return;
+    }
+    nms_sweep_body(n, cb, m, m + (long long)n * cb, keep + first, count + blockIdx.x);
+}
+
 static int nms_sorted_impl(const float *boxes_sorted, int n, float thresh, int plus_one, uint64_t *mask_ws,
                            int64_t *keep, int32_t *count, void *stream);
 
@@ -423,6 +469,24 @@ static int nms_sorted_impl(const float *boxes_sorted, int n, float thresh, int p
         hipLaunchKernelGGL(k_nms_mask<0>, dim3(cb, cb), dim3(64), 0, (hipStream_t)stream, n, thresh, boxes_sorted, mask);
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, (hipStream_t)stream, n, cb, mask,
                        mask + (long long)n * cb, (long long *)keep, count);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_nms_segments_plain(const float *boxes_sorted, const int64_t *seg, int n_seg, int n_max,
+                                        float thresh, uint64_t *mask_ws, int64_t *keep, int32_t *count,
+                                        void *stream)
+{
+    DANCE_REQUIRE(n_seg >= 0 && n_seg <= 65535 && n_max >= 0 && n_max <= (1 << 20));
+    if (n_seg == 0)
+        return 0;
+    DANCE_REQUIRE(seg && count);
+    DANCE_REQUIRE(n_max == 0 || (boxes_sorted && mask_ws && keep));
+    const int cb = (n_max + 63) / 64;
+    if (cb > 0)
+        hipLaunchKernelGGL(k_nms_mask_seg<0>, dim3(cb, cb, n_seg), dim3(64), 0, (hipStream_t)stream,
+                           (const long long *)seg, thresh, boxes_sorted, (unsigned long long *)mask_ws);
+    hipLaunchKernelGGL(k_nms_sweep_seg, dim3(n_seg), dim3(64), 0, (hipStream_t)stream, (const long long *)seg,
+                       (unsigned long long *)mask_ws, (long long *)keep, count);
     return launch_check(__func__);
 }
 

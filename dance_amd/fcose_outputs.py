@@ -117,56 +117,101 @@ class FCOSEOutputs(object):
         raise NotImplementedError("dance_amd.FCOSEOutputs covers inference (predict_proposals); "
                                   "training losses are outside the contour path's scope")
 
-    def _boxlists(self, fields, bounds, image_sizes):
-        """Per image and level the reference's result of forward_for_single_feature_map
-        (fcose_outputs.py:472-521), including its top-k when a level has more candidates than
-        pre_nms_top_n (492-499; `sorted=False`: the order among the kept is unspecified there)."""
-        out = []
-        for i, b in enumerate(bounds):
-            per_level = []
+    def _boxlist(self, fields, b, image_size):
+        """One image: the reference's forward_for_single_feature_map results of the levels in
+        `b` (fcose_outputs.py:472-521), already concatenated as predict_proposals does (438-439).
+        The candidates of an image are contiguous in level order, so this is a slice -- or an
+        index when a level has more candidates than pre_nms_top_n and the reference's top-k
+        applies (492-499; `sorted=False`: the order among the kept is unspecified there)."""
+        sel = slice(b[0], b[-1])
+        if any(b[l + 1] - b[l] > self.pre_nms_top_n for l in range(len(b) - 1)):
+            parts = []
             for l in range(len(b) - 1):
                 lo, hi = b[l], b[l + 1]
-                sel = slice(lo, hi)
                 if hi - lo > self.pre_nms_top_n:
-                    sel = torch.topk(fields["raw"][lo:hi], self.pre_nms_top_n, sorted=False)[1] + lo
-                box = self._boxes(fields["boxes"][sel])
-                inst = self._instances(image_sizes[i])
-                inst.pred_boxes = box
-                inst.scores = fields["scores"][sel]
-                inst.pred_classes = fields["classes"][sel]
-                inst.locations = fields["locations"][sel]
-                if fields["ext"] is not None:
-                    inst.ext_points = self._ext(fields["ext"][sel])
-                per_level.append(inst)
-            out.append(per_level)
-        return out
+                    parts.append(torch.topk(fields["raw"][lo:hi], self.pre_nms_top_n, sorted=False)[1] + lo)
+                else:
+                    parts.append(torch.arange(lo, hi, device=fields["raw"].device))
+            sel = torch.cat(parts)
+        inst = self._instances(image_size)
+        inst.pred_boxes = self._boxes(fields["boxes"][sel])
+        inst.scores = fields["scores"][sel]
+        inst.pred_classes = fields["classes"][sel]
+        inst.locations = fields["locations"][sel]
+        if fields["ext"] is not None:
+            inst.ext_points = self._ext(fields["ext"][sel])
+        return inst
 
     def forward_for_single_feature_map(self, locations, box_cls, reg_pred, ext_pred, ctrness, image_sizes):
         """fcose_outputs.py:444-521 for one level; `reg_pred` already multiplied by the level's
         stride as predict_proposals does (431)."""
         fields, bounds = decode_candidates([locations], [box_cls], [reg_pred], None if ext_pred is None else [ext_pred],
                                            [ctrness], [1.0], self.pre_nms_thresh, self.thresh_with_ctr)
-        return [per_level[0] for per_level in self._boxlists(fields, bounds, image_sizes)]
+        return [self._boxlist(fields, b, image_sizes[i]) for i, b in enumerate(bounds)]
 
     def predict_proposals(self):
         """fcose_outputs.py:419-442."""
         fields, bounds = decode_candidates(self.locations, self.logits_pred, self.reg_pred, self.ext_pred,
                                            self.ctrness_pred, self.strides, self.pre_nms_thresh,
                                            self.thresh_with_ctr)
-        boxlists = [self._instances.cat(per_level) for per_level in self._boxlists(fields, bounds, self.image_sizes)]
+        boxlists = [self._boxlist(fields, b, self.image_sizes[i]) for i, b in enumerate(bounds)]
         return self.select_over_all_levels(boxlists)
 
     def select_over_all_levels(self, boxlists):
         """fcose_outputs.py:523-542: multi-class NMS, then the fpn_post_nms_top_n best by score
-        (ties at the threshold all stay, as with the reference's `>=`)."""
+        (ties at the threshold all stay, as with the reference's `>=`).  The NMS of all images
+        runs as one segmented call (ml_nms.batched_nms_many); the survivors come back in
+        decreasing score, so the reference's kthvalue / `>=` selection is a prefix of them."""
+        if self.nms_thresh <= 0 or not boxlists:
+            return [self._cut_unsorted(b) for b in boxlists]
+        keeps = _ml_nms.batched_nms_many([b.pred_boxes.tensor for b in boxlists], [b.scores for b in boxlists],
+                                         [b.pred_classes for b in boxlists], self.nms_thresh)
+        # one gather per field for all images, then per-image views (instead of one indexing
+        # kernel per field and image)
+        dev = keeps[0].device
+        sizes, kept = [len(b) for b in boxlists], [int(k.numel()) for k in keeps]
+        starts = [0]
+        for n in sizes:
+            starts.append(starts[-1] + n)
+        index = torch.cat([k + st for k, st in zip(keeps, starts)])
+        top, keep_n = self.fpn_post_nms_top_n, list(kept)
+        over = [i for i, m in enumerate(kept) if m > top > 0]
+        offs = [0]
+        for m in kept:
+            offs.append(offs[-1] + m)
+        if over:
+            # how many scores reach the top-th best (>= : ties stay): one host copy for all images
+            sc = torch.cat([b.scores for b in boxlists])[index]
+            seg = torch.repeat_interleave(torch.arange(len(kept), device=dev), torch.tensor(kept, device=dev),
+                                          output_size=offs[-1])
+            kth = sc[torch.tensor([offs[i] + top - 1 if i in over else offs[i] for i in range(len(kept))],
+                                  device=dev).clamp_(max=max(offs[-1] - 1, 0))]
+            tied = torch.zeros(len(kept), dtype=torch.int64, device=dev).scatter_add_(
+                0, seg, (sc >= kth[seg]).to(torch.int64)).tolist()
+            for i in over:
+                keep_n[i] = tied[i]
+        fields = {}
+        for name, v0 in boxlists[0].get_fields().items():
+            vals = [b.get_fields()[name] for b in boxlists]
+            if isinstance(v0, torch.Tensor):
+                fields[name] = (None, torch.cat(vals)[index])
+            else:
+                fields[name] = (type(v0), torch.cat([v.tensor for v in vals])[index])
         results = []
-        for boxlist in boxlists:
-            result = _ml_nms.ml_nms(boxlist, self.nms_thresh)
-            number_of_detections = len(result)
-            if number_of_detections > self.fpn_post_nms_top_n > 0:
-                cls_scores = result.scores
-                image_thresh, _ = torch.kthvalue(cls_scores.cpu(), number_of_detections - self.fpn_post_nms_top_n + 1)
-                keep = torch.nonzero(cls_scores >= image_thresh.item()).squeeze(1)
-                result = result[keep]
-            results.append(result)
+        for i, b in enumerate(boxlists):
+            r = type(b)(b.image_size)
+            for name, (cls, t) in fields.items():
+                piece = t[offs[i]:offs[i] + keep_n[i]]
+                setattr(r, name, piece if cls is None else cls(piece))
+            results.append(r)
         return results
+
+    def _cut_unsorted(self, result):
+        """The reference's cut on a list in arbitrary order (nms_thresh <= 0: ml_nms returns its
+        input, ml_nms.py:20-21)."""
+        number_of_detections = len(result)
+        if number_of_detections > self.fpn_post_nms_top_n > 0:
+            cls_scores = result.scores
+            image_thresh, _ = torch.kthvalue(cls_scores.cpu(), number_of_detections - self.fpn_post_nms_top_n + 1)
+            result = result[torch.nonzero(cls_scores >= image_thresh.item()).squeeze(1)]
+        return result

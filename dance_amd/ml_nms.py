@@ -46,3 +46,44 @@ def ml_nms(boxlist, nms_thresh, max_proposals=-1, score_field="scores", label_fi
     if max_proposals > 0:
         keep = keep[:max_proposals]
     return boxlist[keep]
+
+
+def batched_nms_many(boxes, scores, idxs, iou_threshold):
+    """`batched_nms` of several independent lists (one per image) at once: lists of (n_i,4),
+    (n_i,), (n_i,) -> list of int64 index tensors, each exactly what batched_nms(boxes[i],
+    scores[i], idxs[i]) returns (the class offset uses the list's own largest coordinate, the
+    order is decreasing score, ties in input order).  Two stable sorts and two launches for all
+    lists (`dance_nms_segments_plain`), one host sync for the kept counts."""
+    sizes = [int(b.size(0)) for b in boxes]
+    total, n_seg = sum(sizes), len(sizes)
+    if n_seg == 0:
+        return []
+    dev = boxes[0].device
+    if total == 0:
+        return [torch.empty((0,), dtype=torch.int64, device=dev) for _ in sizes]
+    if not dev.type == "cuda":
+        raise RuntimeError("dance_amd.ml_nms needs GPU tensors (got a %s tensor)" % dev)
+    starts, ws_off, seg_rows = [0], [0], []
+    for n in sizes:
+        seg_rows.append((starts[-1], n, ws_off[-1]))
+        starts.append(starts[-1] + n)
+        ws_off.append(ws_off[-1] + (n + 1) * ((n + 63) // 64))
+    seg = torch.tensor(seg_rows, dtype=torch.int64).to(dev, non_blocking=True)
+    b_all = torch.cat([b.float().reshape(-1, 4) for b in boxes])
+    s_all = torch.cat([x.float() for x in scores])
+    c_all = torch.cat(list(idxs))
+    seg_id = torch.repeat_interleave(torch.arange(n_seg, device=dev), torch.tensor(sizes, device=dev),
+                                     output_size=total)
+    top = torch.full((n_seg,), float("-inf"), device=dev).scatter_reduce_(0, seg_id, b_all.amax(1), "amax")
+    offsets = c_all.to(b_all) * (top + 1)[seg_id]
+    by_score = torch.sort(s_all, descending=True, stable=True)[1]
+    order = by_score[torch.sort(seg_id[by_score], stable=True)[1]]           # image-major, score-descending
+    rows = torch.cat([b_all + offsets[:, None], s_all[:, None]], 1)[order].contiguous()
+    ws = torch.empty((ws_off[-1],), dtype=torch.int64, device=dev)
+    keep = torch.empty((total,), dtype=torch.int64, device=dev)
+    count = torch.empty((n_seg,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().dance_nms_segments_plain(ptr(rows), ptr(seg), n_seg, max(sizes), float(iou_threshold), ptr(ws),
+                                             ptr(keep), ptr(count), current_stream()), "batched_nms_many")
+    counts = count.tolist()
+    return [order[starts[i] + keep[starts[i]:starts[i] + counts[i]]] - starts[i] for i in range(n_seg)]

@@ -73,6 +73,16 @@ int dance_nms_sorted(const float *boxes_sorted, int n, float thresh, uint64_t *m
 int dance_nms_sorted_plain(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
                            int64_t *keep, int32_t *count, void *stream);
 
+/* dance_nms_sorted_plain for many independent lists in two launches -- the per-image loop of
+ * select_over_all_levels (fcose_outputs.py:523-529) without a launch pair and a host sync per
+ * image.  boxes_sorted: the segments' (n_i,5) rows back to back, each sorted by descending score;
+ * seg (n_seg,3) i64 on the device: first row, n_i, first mask word of segment i (segment i needs
+ * (n_i + 1) * ceil(n_i/64) words of mask_ws); n_max = largest n_i; keep (sum n_i) i64: kept
+ * positions relative to the segment, written from the segment's first row; count (n_seg) i32. */
+int dance_nms_segments_plain(const float *boxes_sorted, const int64_t *seg, int n_seg, int n_max,
+                             float thresh, uint64_t *mask_ws, int64_t *keep, int32_t *count,
+                             void *stream);
+
 /* reference: snake_head.py:1752-1761 (`RefineNet.contour_upsample_2x`, used only with
  * LAST_UP_SAMPLE).  loc (n,v,2) f32 -> out (n,2v,2): even slots copy, odd slots are the
  * mid-points (p[i] + p[i+1 mod v]) / 2, rounded as the reference's add-then-divide. */

@@ -205,3 +205,31 @@ def test_ml_nms_against_the_oracle(device, n):
     assert torch.equal(out.scores.cpu(), scores[want]) and torch.equal(out.pred_boxes.tensor.cpu(), boxes[want])
     assert ml_nms.ml_nms(inst, 0.0) is inst
     assert ml_nms.batched_nms(boxes[:0].to(device), scores[:0].to(device), classes[:0].to(device), 0.5).numel() == 0
+
+
+def test_batched_nms_many_equals_one_call_per_list(device):
+    """The segmented NMS (one call for all images) returns, list by list, exactly what
+    batched_nms returns for that list alone and what the C oracle returns: sizes around the
+    64-box tile edge, an empty list, heavy overlap, repeated scores (ties keep input order)."""
+    from dance_amd import ml_nms
+    g = torch.Generator().manual_seed(17)
+    boxes, scores, idxs = [], [], []
+    for n in (300, 0, 1, 64, 65, 1000, 129):
+        xy = torch.rand(n, 2, generator=g) * 200
+        wh = torch.rand(n, 2, generator=g) * 80 + 4
+        boxes.append(torch.cat([xy, xy + wh], 1))
+        s = torch.rand(n, generator=g)
+        if n >= 64:
+            s[::7] = s[3]                                  # ties
+        scores.append(s)
+        idxs.append(torch.randint(0, 3, (n,), generator=g))
+    many = ml_nms.batched_nms_many([b.to(device) for b in boxes], [s.to(device) for s in scores],
+                                   [i.to(device) for i in idxs], 0.5)
+    assert len(many) == len(boxes)
+    for b, s, i, got in zip(boxes, scores, idxs, many):
+        one = ml_nms.batched_nms(b.to(device), s.to(device), i.to(device), 0.5)
+        assert torch.equal(got, one)
+        assert torch.equal(got.cpu(), cref.batched_nms(b, s, i, 0.5))
+    assert ml_nms.batched_nms_many([], [], [], 0.5) == []
+    empty = ml_nms.batched_nms_many([boxes[1].to(device)] * 2, [scores[1].to(device)] * 2, [idxs[1].to(device)] * 2, 0.5)
+    assert [e.numel() for e in empty] == [0, 0]

@@ -33,6 +33,23 @@ def main():
     nbytes = sum(n * (c + 1) * h * w * 4 for h, w in shapes)
     print("candidates %d  wall %.3f ms  logits+ctr %.1f MB per pass" % (fields["scores"].numel(), ms, nbytes / 1e6))
 
+    class Images:
+        image_sizes = [(800, 1216)] * n
+
+        def __len__(self):
+            return n
+
+    out = fcose_outputs.FCOSEOutputs(Images(), loc, logits, reg, ext, ctr, 0.25, 2.0, None, None, True, None, strides,
+                                     1.5, c, th, 1000, 0.6, 100, True)
+    res = out.predict_proposals()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        res = out.predict_proposals()
+    torch.cuda.synchronize()
+    print("predict_proposals (decode + top-k + ml_nms + cut, %d images): %.3f ms, %s detections"
+          % (n, (time.perf_counter() - t0) * 1e3 / 5, [len(r) for r in res][:4]))
+
 
 if __name__ == "__main__":
     main()
