@@ -24,4 +24,6 @@ python3 tools/pmc_summary.py $KEEP/pmc1_*counter_collection.csv $KEEP/pmc1_*kern
 python3 tools/pmc_summary.py $KEEP/pmc2_*counter_collection.csv $KEEP/pmc2_*kernel_trace.csv > $KEEP/summary_pmc2.txt
 python3 tools/pmc_summary.py $KEEP/pmc3_*counter_collection.csv $KEEP/pmc3_*kernel_trace.csv > $KEEP/summary_pmc3.txt
 python3 tools/traffic_json.py $KEEP/pmc2_*counter_collection.csv $KEEP/pmc3_*counter_collection.csv $TAG $KEEP/hbm_traffic.json > /dev/null
+# the raw per-dispatch tables stay on the box: gpurun_out travels back only below 64 MiB
+rm -f $KEEP/*_counter_collection.csv $KEEP/*_kernel_trace.csv
 ls -la $KEEP
