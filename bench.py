@@ -427,7 +427,7 @@ def main():
         fcose_fig = {"stage": "FCOSE decode of %d images x 5 levels (800x1216) x %d classes: sigmoid scores x centerness, "
                               "threshold %.2f, compaction in `nonzero` order, box + extreme-point decode; outside the "
                               "timed step" % (b, fc_c, fc_th),
-                     "kernel": "k_fcose_count + torch.cumsum + k_fcose_fill (5 + 5 launches)", "candidates": int(
+                     "kernel": "k_fcose_count + torch.cumsum + k_fcose_fill (one launch each for all levels)", "candidates": int(
                          fc_fields["scores"].numel()), "ms_wall_incl_one_sync": fc_ms,
                      "algorithmic_GBps": fc_bytes / fc_ms / 1e6, "stock_torch_ms": fc_stock_ms,
                      "speedup_vs_stock": fc_stock_ms / fc_ms, "stock_candidates": fc_n,
