@@ -468,13 +468,15 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         total_flops = 2.0 * MACS_PER_VERTEX * v * n * ITERS
         rt = 2 if v <= 64 else 4 if v <= 128 else 7 if v <= 224 else 8
+        # dance_res_stack16's dispatch: 8-wave kernel above 128 vertices and for few long rings
+        stack_wide = v > 128 or (v > 96 and n <= int(os.environ.get("DANCE_STACK_SMALL_N", "256")))
         if args.precision in ("fp16x3", "fp16"):
             terms = 3 if args.precision == "fp16x3" else 1
             # every algorithmic product is three f16 MFMA products (A_lo*B_hi + A_hi*B_lo +
             # A_hi*B_hi); the roofline prices the EXECUTED f16 MFMA flops against the f16 peak
             kname = ("k_head_stack16s<%d,%d> (gather + head SnakeBlock 258->128 + the 7 residual SnakeBlocks "
                      "128->128, k=9, in one launch; %s f16 MFMA)" if head_stack else
-                     ("k_res_stack16s" if v <= 128 else "k_res_stack16w") +
+                     ("k_res_stack16w" if stack_wide else "k_res_stack16s") +
                      "<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
                      "%s f16 MFMA 16x16x32)" if stacked else
                      "k_conv16%s<%d,%d> (residual SnakeBlock 128->128, k=9, %s f16 MFMA; 7 launches "
@@ -493,7 +495,7 @@ def main():
                             "inter-kernel gap, ~10 us per launch)" % terms}
             if terms == 3:
                 roof["traffic"], roof["traffic_source"] = measured_traffic(
-                    "k_head_stack16s" if head_stack else ("k_res_stack16s" if v <= 128 else "k_res_stack16w")
+                    "k_head_stack16s" if head_stack else ("k_res_stack16w" if stack_wide else "k_res_stack16s")
                     if stacked else
                     "k_conv16s" if rt <= 4 else "k_conv16<", n)
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"

@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
 template <int RT, int TERMS>
 __device__ __forceinline__ void res_stack16w_body(const Stack16Args &a, int n)
 {
-    static_assert(RT == 7 || RT == 8, "rings of 129..256 vertices");
+    static_assert(RT == 4 || RT == 7 || RT == 8, "rings of 97..128 (few contours) or 129..256 vertices");
     constexpr int CBC = 8, NST = CBC / 4, AD = 2, NW = 8, CTW = RT, NB = (NST * CTW) % 4 == 0 ? 4 : 2;
     using G = Geo<RT, CBC>;
     using S = StageGeo<RT, CBC, NW>;
@@ -1448,9 +1448,15 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
     }
     const int rt = pick_rt16(v);
     const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // the whole 128-channel image
-    if (rt > 4) {                                                  // 129..256 vertices: 8 waves, one workgroup per CU
+    // few contours (the reference's one-image inference: ~100 instances on 256 CUs): a contour per
+    // CU either way, so it gets 8 waves instead of 4 (-9 % on the stack at n = 100; same products
+    // and summation order as k_res_stack16s, bit-identical).  DANCE_STACK_SMALL_N = largest such n.
+    static const int small_n = env_int("DANCE_STACK_SMALL_N", 256);
+    if (rt > 4 || (rt == 4 && n <= small_n)) {                     // 129..256 vertices: 8 waves, one workgroup per CU
         int rc_ = 0;
-        if (rt == 7)
+        if (rt == 4)
+            LAUNCH_ONE(k_res_stack16w, 4, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else if (rt == 7)
             LAUNCH_ONE(k_res_stack16w, 7, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
         else
             LAUNCH_ONE(k_res_stack16w, 8, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);

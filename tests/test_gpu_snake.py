@@ -280,9 +280,10 @@ def test_res_stack_equals_seven_launches(device, v):
     cfg, sd, _ = dance_state_dict(99, 128)
     net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
     s16 = net.struct16
-    n, slot = 37, 256 * v
-    x = torch.randn((n, 128, v), generator=torch.Generator().manual_seed(v)) * 2
-    for terms in (3, 1):
+    slot = 256 * v
+    # 97..128 vertices: up to 256 contours run the 8-wave kernel, more the 4-wave one -- cover both
+    for n, terms in [(37, 3), (37, 1)] + ([(300, 3), (300, 1)] if 96 < v <= 128 else []):
+        x = torch.randn((n, 128, v), generator=torch.Generator().manual_seed(v)) * 2
         a = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
         a[:, 0] = ops.to_p16(x.to(device))[:, 0]
         b = a.clone()
