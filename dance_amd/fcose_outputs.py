@@ -164,6 +164,13 @@ class FCOSEOutputs(object):
         decreasing score, so the reference's kthvalue / `>=` selection is a prefix of them."""
         if self.nms_thresh <= 0 or not boxlists:
             return [self._cut_unsorted(b) for b in boxlists]
+        if len(boxlists) == 1:
+            # one image (the reference's inference mode): the per-image call has fewer launches
+            result = _ml_nms.ml_nms(boxlists[0], self.nms_thresh)
+            top = self.fpn_post_nms_top_n
+            if len(result) > top > 0:
+                result = result[:int((result.scores >= result.scores[top - 1]).sum())]
+            return [result]
         keeps = _ml_nms.batched_nms_many([b.pred_boxes.tensor for b in boxlists], [b.scores for b in boxlists],
                                          [b.pred_classes for b in boxlists], self.nms_thresh)
         # one gather per field for all images, then per-image views (instead of one indexing

@@ -190,3 +190,27 @@ def test_full_size_counts_and_boxes():
         box = torch.stack([loc[:, 0] - r[:, 0], loc[:, 1] - r[:, 1], loc[:, 0] + r[:, 2], loc[:, 1] + r[:, 3]], 1)
         assert torch.equal(fields["boxes"][lo:hi], box)
         assert bool((fields["scores"][lo:hi] ** 2 > th * (1 - 1e-5)).all())
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_single_image_path_golden(case):
+    """One image per call (the reference's inference mode) takes the per-image NMS branch: the
+    fixture's images one at a time give the fixture's results."""
+    from dance_amd.fcose_outputs import compute_locations
+    tag, th, with_ctr, pre, nms_th, post = case
+    g = golden("g11_fcose")
+    dev = torch.device("cuda:0")
+    strides = [s for _, s in LEVELS]
+    sizes = [(96, 128), (90, 120)]
+    for i in range(2):
+        t = lambda k: g[k][i:i + 1].to(dev)
+        logits = [t("%s_logits%d" % (tag, l)) for l in range(3)]
+        res = _outputs(compute_locations(logits, strides), logits, [t("%s_reg%d" % (tag, l)) for l in range(3)],
+                       [t("%s_ext%d" % (tag, l)) for l in range(3)], [t("%s_ctr%d" % (tag, l)) for l in range(3)],
+                       strides, th, with_ctr, pre, nms_th, post, sizes[i:i + 1]).predict_proposals()
+        assert len(res) == 1
+        r = res[0]
+        assert torch.equal(r.pred_classes.cpu(), g["%s_im%d_classes" % (tag, i)])
+        assert torch.equal(r.pred_boxes.tensor.cpu(), g["%s_im%d_boxes" % (tag, i)])
+        assert torch.equal(r.ext_points.tensor.cpu(), g["%s_im%d_ext" % (tag, i)])
+        assert _score_close(r.scores.cpu(), g["%s_im%d_scores" % (tag, i)])
