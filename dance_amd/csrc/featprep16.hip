@@ -49,6 +49,43 @@ __global__ __launch_bounds__(256) void k_nchw_to_p16img(const float *__restrict_
     *reinterpret_cast<h8 *>(d + (long long)cbt * hw * 8) = lo;
 }
 
+// the same from an NHWC (channels_last) source: what a previous layer of this file, or torch on
+// channels_last tensors, hands over -- no NCHW round trip between the layers of a head.
+// thread = one pixel of one 8-channel block, the 8-channel blocks fastest (32-byte reads side
+// by side along a pixel's channels; the 16-byte writes of 8 neighbouring pixels form a line)
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_nhwc_to_p16img(const float *__restrict__ src, int c_total, int c_off,
+                                                        _Float16 *__restrict__ dst, int c, long long hw)
+{
+    const int cbt = c >> 3, b = blockIdx.y;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= hw * cbt)
+        return;
+    const long long p = i / cbt;
+    const int cb = (int)(i - p * cbt);
+    const float *s = src + ((long long)b * hw + p) * c_total + c_off + cb * 8;
+    float x[8];
+    if (VEC) {
+        const float4 a = *reinterpret_cast<const float4 *>(s), e = *reinterpret_cast<const float4 *>(s + 4);
+        x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = e.x, x[5] = e.y, x[6] = e.z, x[7] = e.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            x[j] = s[j];
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 u, v;
+        dance::split_half(x[j], u, v);
+        hi[j] = u;
+        lo[j] = v;
+    }
+    _Float16 *d = dst + (((long long)b * 2 * cbt + cb) * hw + p) * 8;
+    *reinterpret_cast<h8 *>(d) = hi;
+    *reinterpret_cast<h8 *>(d + (long long)cbt * hw * 8) = lo;
+}
+
 // ---------------------------------------------------------------------------- conv 3x3
 struct Conv2dArgs {
     const _Float16 *x;      // P16 image
@@ -309,6 +346,25 @@ extern "C" int dance_nchw_to_p16img(const float *src, int c_total, int c_off, vo
     const long long hw = (long long)h * w;
     hipLaunchKernelGGL(k_nchw_to_p16img, dim3((unsigned)((hw + 255) / 256), c / 8, b), dim3(256), 0,
                        (hipStream_t)stream, src, c_total, c_off, (_Float16 *)dst16, c, hw);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_nhwc_to_p16img(const float *src, int c_total, int c_off, void *dst16, int b, int c,
+                                    int h, int w, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && c >= 8 && c % 8 == 0 && h >= 1 && w >= 1 && c_off >= 0 && c_off + c <= c_total);
+    if (b == 0)
+        return 0;
+    DANCE_REQUIRE(src && dst16 && b <= 65535);
+    const long long hw = (long long)h * w, items = hw * (c / 8);
+    DANCE_REQUIRE((items + 255) / 256 < (1ll << 31));
+    const dim3 grid((unsigned)((items + 255) / 256), b);
+    if (c_total % 4 == 0 && c_off % 4 == 0 && ((uintptr_t)src & 15) == 0)
+        hipLaunchKernelGGL(k_nhwc_to_p16img<true>, grid, dim3(256), 0, (hipStream_t)stream, src, c_total, c_off,
+                           (_Float16 *)dst16, c, hw);
+    else
+        hipLaunchKernelGGL(k_nhwc_to_p16img<false>, grid, dim3(256), 0, (hipStream_t)stream, src, c_total, c_off,
+                           (_Float16 *)dst16, c, hw);
     return launch_check(__func__);
 }
 

@@ -250,7 +250,12 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
     are skipped); layers = [(w16, scale_pow2, gamma, beta), ...] with w16 from
     `pack_conv3x3_weight16`.  Returns the NHWC fp32 map (B, H, W, C) the gather kernels read."""
     _need_gpu(features)
-    features = _f32c(features)
+    # a channels_last tensor (what this function's own output viewed as NCHW, an upsampling or a
+    # sum of such tensors is) is read in place: no NCHW copy between the layers of a head
+    nhwc_in = (features.dim() == 4 and features.dtype == torch.float32 and not features.is_contiguous()
+               and features.permute(0, 2, 3, 1).is_contiguous())
+    if not nhwc_in:
+        features = _f32c(features)
     b, ct, h, w = features.shape
     c = ct - c_off
     dev = features.device
@@ -262,7 +267,8 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
     out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         st = current_stream()
-        check(lib().dance_nchw_to_p16img(ptr(features), ct, c_off, ptr(x16), b, c, h, w, st), "nchw_to_p16img")
+        to_p16 = lib().dance_nhwc_to_p16img if nhwc_in else lib().dance_nchw_to_p16img
+        check(to_p16(ptr(features), ct, c_off, ptr(x16), b, c, h, w, st), "to_p16img")
         for i, (w16, scale, gamma, beta) in enumerate(layers):
             if w16.shape[2] * 8 != c or w16.shape[3] != c:
                 raise ValueError("bottom_out layers are C -> C")

@@ -98,6 +98,11 @@ int dance_contour_upsample_2x(const float *loc, float *out, int n, int v, void *
  *   dst16 "P16 image" [b][plane hi/lo][c/8][h][w][8] fp16 (4 bytes per element). */
 int dance_nchw_to_p16img(const float *src, int c_total, int c_off, void *dst16, int b, int c,
                          int h, int w, void *stream);
+/* dance_nhwc_to_p16img: the same from an NHWC (channels_last) source (b, h, w, c_total): the
+ *   layout dance_gn_relu's out_nhwc and torch's channels_last tensors have, so consecutive
+ *   conv3x3 + GN + ReLU layers of the semantic-FPN head (edge_det.py:106-138) need no NCHW copy. */
+int dance_nhwc_to_p16img(const float *src, int c_total, int c_off, void *dst16, int b, int c,
+                         int h, int w, void *stream);
 /* dance_conv3x3_16: raw 3x3 convolution (zero padding 1, no bias) of a P16 image with weights
  *   packed [plane][tap ky*3+kx][cin/8][cout][8] fp16 of w * 2^s (w_inv_scale = 2^-s).
  *   y_blocked (b, cout/16, h, w, 16) fp32; stats (b, groups, 2) f64 = per-group sum and sum of

@@ -48,6 +48,14 @@ def test_bottom_out_shapes_vs_oracle(device, shape):
         want = snake_ref.bottom_out(sub, feats[:, 1:]).permute(0, 2, 3, 1)
         got = ops.bottom_out16(feats.to(device), 1, _layers(sd, device, n))
         assert rel_err(got, want) < 1e-4, (shape, n)
+        # the same tensor in channels_last memory is read in place (dance_nhwc_to_p16img):
+        # 257 channels with the attention plane skipped (scalar loads), 256 (16-byte loads)
+        cl = feats.to(device).contiguous(memory_format=torch.channels_last)
+        assert torch.equal(ops.bottom_out16(cl, 1, _layers(sd, device, n)), got)
+        cl = feats[:, 1:].to(device).contiguous(memory_format=torch.channels_last)
+        if h * w > 1:
+            assert not cl.is_contiguous()
+        assert torch.equal(ops.bottom_out16(cl, 0, _layers(sd, device, n)), got)
 
 
 def test_module_bottom_out_feeds_the_gather(device):
