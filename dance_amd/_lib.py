@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -71,6 +71,7 @@ SIGNATURES = {
     "dance_roll_array": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "dance_nchw_to_p16img": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "dance_nhwc_to_p16img": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "dance_upsample2x_add": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_conv3x3_16": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_nms_sorted": (c_int, [P, c_int, c_float, P, P, P, P]),

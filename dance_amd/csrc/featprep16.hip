@@ -86,6 +86,37 @@ __global__ __launch_bounds__(256) void k_nhwc_to_p16img(const float *__restrict_
     *reinterpret_cast<h8 *>(d + (long long)cbt * hw * 8) = lo;
 }
 
+// ------------------------------------------------------------------- upsample x2 (+ sum)
+// out = acc + bilinear_x2(src), NHWC fp32: the last nn.Upsample(scale_factor=2, bilinear,
+// align_corners=False) of a semantic-FPN scale head and the sum over the levels that follows it
+// (edge_det.py:118-125, 188-194) in one pass.  Source index as torch computes it:
+// max(0.5 * (dst + 0.5) - 0.5, 0).  grid (ceil(2w * c/4 / 256), 2h, b); thread = one float4.
+__global__ __launch_bounds__(256) void k_upsample2x_add(const float *__restrict__ src, const float *acc,
+                                                        float *out, int h, int w, int c4)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * w * c4)
+        return;
+    const int ox = i / c4, cq = i - ox * c4, oy = blockIdx.y, b = blockIdx.z;
+    const float fy = fmaxf(0.5f * ((float)oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(0.5f * ((float)ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx, y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float4 *s = reinterpret_cast<const float4 *>(src) + (long long)b * h * w * c4 + cq;
+    const float4 v00 = s[((long long)y0 * w + x0) * c4], v01 = s[((long long)y0 * w + x1) * c4];
+    const float4 v10 = s[((long long)y1 * w + x0) * c4], v11 = s[((long long)y1 * w + x1) * c4];
+    float4 r;
+    r.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    r.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    r.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    r.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    const long long o = (((long long)b * 2 * h + oy) * 2 * w + ox) * c4 + cq;
+    if (acc) {
+        const float4 a = reinterpret_cast<const float4 *>(acc)[o];
+        r.x += a.x, r.y += a.y, r.z += a.z, r.w += a.w;
+    }
+    reinterpret_cast<float4 *>(out)[o] = r;
+}
+
 // ---------------------------------------------------------------------------- conv 3x3
 struct Conv2dArgs {
     const _Float16 *x;      // P16 image
@@ -365,6 +396,21 @@ extern "C" int dance_nhwc_to_p16img(const float *src, int c_total, int c_off, vo
     else
         hipLaunchKernelGGL(k_nhwc_to_p16img<false>, grid, dim3(256), 0, (hipStream_t)stream, src, c_total, c_off,
                            (_Float16 *)dst16, c, hw);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_upsample2x_add(const float *src, const float *acc, float *out, int b, int h, int w, int c,
+                                    void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && h >= 1 && w >= 1 && c >= 4 && c % 4 == 0);
+    if (b == 0)
+        return 0;
+    DANCE_REQUIRE(src && out && b <= 65535 && 2 * h <= 65535);
+    DANCE_REQUIRE((((uintptr_t)src | (uintptr_t)acc | (uintptr_t)out) & 15) == 0);
+    const long long row = 2ll * w * (c / 4);
+    DANCE_REQUIRE(row < (1ll << 31) - 256);
+    hipLaunchKernelGGL(k_upsample2x_add, dim3((unsigned)((row + 255) / 256), 2 * h, b), dim3(256), 0,
+                       (hipStream_t)stream, src, acc, out, h, w, c / 4);
     return launch_check(__func__);
 }
 

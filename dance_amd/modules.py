@@ -522,14 +522,31 @@ class EdgeSnakeFPNHead(nn.Module):
                                            nn.Conv2d(conv_dims, num_classes, kernel_size=1))
         self.refine_head = RefineNet(cfg, polygon_cls=polygon_cls)
 
+    @staticmethod
+    def _add_scale_head(head, feat, x):
+        """x + head(feat) (edge_det.py:188-194).  When the head ends in its x2 upsampling and both
+        sides are channels_last GPU tensors (the HIP conv layers' output), that upsampling and the
+        sum are one launch, written into x."""
+        mods = list(head)
+        if (x is not None and isinstance(mods[-1], nn.Upsample) and _ConvNormAct.use_hip and feat.is_cuda
+                and not torch.is_grad_enabled() and os.environ.get("DANCE_FEATPREP", "hip") == "hip"):
+            y = feat
+            for m in mods[:-1]:
+                y = m(y)
+            if (ops.is_nhwc(y) and ops.is_nhwc(x) and y.size(1) % 4 == 0
+                    and tuple(x.shape) == (y.size(0), y.size(1), 2 * y.size(2), 2 * y.size(3))):
+                return ops.upsample2x_add(y, x, inplace=True)
+            return x + mods[-1](y)
+        y = head(feat)
+        return y if x is None else x + y
+
     def forward(self, features, pred_instances=None, targets=None):
         if self.training:
             raise NotImplementedError("dance_amd.EdgeSnakeFPNHead is inference-only (call .eval())")
         with timer.env("pfpn_back"):
             x = None
             for f, head in zip(self.in_features, self.scale_heads):
-                y = head(features[f])
-                x = y if x is None else x + y
+                x = self._add_scale_head(head, features[f], x)
         with timer.env("edge"):
             pred_edge = self.predictor(x).sigmoid()
             att_map = self.attender(1 - pred_edge) if self.attention else None

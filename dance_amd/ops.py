@@ -281,6 +281,28 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
     return out
 
 
+def is_nhwc(t):
+    """NCHW-shaped fp32 GPU tensor whose memory is dense NHWC (channels_last)."""
+    return (t.dim() == 4 and t.is_cuda and t.dtype == torch.float32 and t.permute(0, 2, 3, 1).is_contiguous())
+
+
+def upsample2x_add(src, acc=None, inplace=False):
+    """acc + F.interpolate(src, scale_factor=2, mode="bilinear", align_corners=False) for
+    channels_last tensors (B,C,H,W) / (B,C,2H,2W), in one launch; acc None: the upsampling
+    alone; inplace: the sum is written into acc.  Returns a channels_last (B,C,2H,2W) tensor."""
+    if not is_nhwc(src) or (acc is not None and not is_nhwc(acc)):
+        raise RuntimeError("upsample2x_add: channels_last fp32 GPU tensors expected")
+    b, c, h, w = src.shape
+    if acc is not None and tuple(acc.shape) != (b, c, 2 * h, 2 * w):
+        raise RuntimeError("upsample2x_add: acc must be (B, C, 2H, 2W)")
+    out = acc if (inplace and acc is not None) else torch.empty((b, 2 * h, 2 * w, c), dtype=torch.float32,
+                                                                device=src.device).permute(0, 3, 1, 2)
+    with torch.cuda.device(src.device):
+        check(lib().dance_upsample2x_add(ptr(src), ptr(acc), ptr(out), b, h, w, c, current_stream()),
+              "upsample2x_add")
+    return out
+
+
 # ---------------------------------------------------------------------------- attender
 def attender(x, w1, gn1_w, gn1_b, w2_packed, gn2_w, gn2_b, w3, b3, eps=1e-5):
     """EdgeSnakeFPNHead.attender (edge_det.py:66-100) on x = 1 - pred_edge, (B,1,H,W) or (B,H,W)

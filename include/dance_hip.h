@@ -103,6 +103,12 @@ int dance_nchw_to_p16img(const float *src, int c_total, int c_off, void *dst16, 
  *   conv3x3 + GN + ReLU layers of the semantic-FPN head (edge_det.py:106-138) need no NCHW copy. */
 int dance_nhwc_to_p16img(const float *src, int c_total, int c_off, void *dst16, int b, int c,
                          int h, int w, void *stream);
+/* dance_upsample2x_add: out (b, 2h, 2w, c) = acc + bilinear x2 of src (b, h, w, c), NHWC fp32,
+ *   align_corners = False -- the last nn.Upsample of a semantic-FPN scale head and the sum over
+ *   the levels (edge_det.py:118-125, 188-194) in one pass.  acc may be NULL (plain upsampling)
+ *   and may be `out` itself (in place).  c % 4 == 0, 16-byte aligned pointers. */
+int dance_upsample2x_add(const float *src, const float *acc, float *out, int b, int h, int w, int c,
+                         void *stream);
 /* dance_conv3x3_16: raw 3x3 convolution (zero padding 1, no bias) of a P16 image with weights
  *   packed [plane][tap ky*3+kx][cin/8][cout][8] fp16 of w * 2^s (w_inv_scale = 2^-s).
  *   y_blocked (b, cout/16, h, w, 16) fp32; stats (b, groups, 2) f64 = per-group sum and sum of

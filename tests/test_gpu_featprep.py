@@ -92,3 +92,26 @@ def test_dsnake_module_with_bottom_out(device):
     prepped = snake_ref.bottom_out(sd, feats)
     want = snake_ref.dsnake_deform(sd, prepped, [boxes[0], boxes[1]])
     assert coord_rel_err(got, want["preds"][-1]) < REL_TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 25, 38), (2, 128, 7, 5), (1, 8, 1, 1), (3, 12, 3, 100)])
+def test_upsample2x_add_vs_torch(device, shape):
+    """acc + bilinear x2 (align_corners=False) in one launch against torch's own two ops on the
+    same GPU: 1e-6 (the four weights are exact; only the summation's contraction differs)."""
+    import torch.nn.functional as F
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    src = torch.randn(b, c, h, w, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    acc = torch.randn(b, c, 2 * h, 2 * w, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    src, acc = src.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), acc.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    up = F.interpolate(src, scale_factor=2, mode="bilinear", align_corners=False)
+    got = ops.upsample2x_add(src)
+    assert got.shape == up.shape and float((got - up).abs().max()) <= 1e-6 * float(up.abs().max())
+    want = acc + up
+    got = ops.upsample2x_add(src, acc)
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    keep = acc.clone()
+    out = ops.upsample2x_add(src, acc, inplace=True)
+    assert out.data_ptr() == acc.data_ptr() and torch.equal(out, got) and not torch.equal(acc, keep)
+    with pytest.raises(RuntimeError):
+        ops.upsample2x_add(src.contiguous() if h * w > 1 and c > 1 else src.cpu())
