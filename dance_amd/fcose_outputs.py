@@ -69,9 +69,10 @@ def decode_candidates(locations, logits_pred, reg_pred, ext_pred, ctrness_pred, 
         check(lib().dance_fcose_count(table, len(hws), ptr(counts), n, c, float(pre_nms_thresh), flag, st), "fcose_count")
         cum = torch.cumsum(counts.view(-1), 0, dtype=torch.int64)
         # segment starts of every (image, level) and the grand total: the one host copy
-        idx = (torch.arange(n, device=dev)[:, None] * total + torch.tensor(lvl_off[:-1], device=dev)[None]).view(-1)
+        # (a segment starts where the inclusive sum stood one slot earlier; the last entry is the total)
         if n * total:
-            starts = (cum[idx] - counts.view(-1)[idx]).tolist() + [int(cum[-1])]
+            ends = [i * total + o - 1 for i in range(n) for o in lvl_off[:-1]][1:] + [n * total - 1]
+            starts = [0] + cum[torch.tensor(ends, device=dev)].tolist()
         else:
             starts = [0] * (n * len(hws) + 1)
         m = starts[-1]
