@@ -402,9 +402,17 @@ __device__ __forceinline__ void nms_sweep_body(int n, int col_blocks, const unsi
         num += __popcll(kept);
         for (int j = kb + 1 + lane; j < col_blocks; j += 64) {
             unsigned long long acc = remv[j];
-            for (int i = 0; i < size; ++i)
-                if ((kept >> i) & 1ull)
-                    acc |= mask[(long long)(kb * 64 + i) * col_blocks + j];
+            // eight independent row loads in flight, masked by the kept bits afterwards (a load
+            // per kept row behind a branch left this loop latency-bound)
+            for (int i0 = 0; i0 < size; i0 += 8) {
+                unsigned long long m[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    m[k] = mask[(long long)(kb * 64 + min(i0 + k, size - 1)) * col_blocks + j];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc |= (i0 + k < size && ((kept >> (i0 + k)) & 1ull)) ? m[k] : 0ull;
+            }
             remv[j] = acc;
         }
         __syncthreads();

@@ -74,7 +74,8 @@ def batched_nms_many(boxes, scores, idxs, iou_threshold):
     c_all = torch.cat(list(idxs))
     seg_id = torch.repeat_interleave(torch.arange(n_seg, device=dev), torch.tensor(sizes, device=dev),
                                      output_size=total)
-    top = torch.full((n_seg,), float("-inf"), device=dev).scatter_reduce_(0, seg_id, b_all.amax(1), "amax")
+    # each list's largest coordinate (an atomic scatter-amax over 16 addresses took 1.3 ms here)
+    top = torch.stack([b.max() if b.numel() else b.new_zeros(()) for b in boxes]).float()
     offsets = c_all.to(b_all) * (top + 1)[seg_id]
     by_score = torch.sort(s_all, descending=True, stable=True)[1]
     order = by_score[torch.sort(seg_id[by_score], stable=True)[1]]           # image-major, score-descending
