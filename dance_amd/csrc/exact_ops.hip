@@ -333,6 +333,8 @@ template <int ONE>
 __device__ __forceinline__ void nms_mask_tile(int n, int col_blocks, int row_start, int col_start, float thresh,
                                               const float *__restrict__ boxes, unsigned long long *__restrict__ mask)
 {
+    if (col_start < row_start)                  // words left of the diagonal are never read by the sweep
+        return;
     const int row_size = min(n - row_start * 64, 64), col_size = min(n - col_start * 64, 64);
     __shared__ float bb[64 * 5];
     if ((int)threadIdx.x < col_size)
