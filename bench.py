@@ -1,13 +1,24 @@
 """Benchmark of the contour-deformation hot path (BASELINE.json metric: contours deformed/sec,
 128 vertices, all iterations; gather HBM GB/s).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (per GPU, weak scaling): BASELINE config 2 -- DANCE R50 snake head, fp32,
-16 images x 100 instances x 128 vertices on synthetic 800x1216 FPN features
-(16, 1+256, 200, 304), attention + individual scale on, 3 deformation iterations.
-One step = the reference's `snake_deformation` scope (snake_head.py:1822-1862) over that
+`--gpus N` with N > 1 and no torch.distributed environment starts the N ranks itself, one
+process per GPU (as the reference's train_net.py:76-83 `launch(main, args.num_gpus, ...)` does):
+the parent never touches the GPU, runs `python -m torch.distributed.run` as a child process and
+exits with its status; rank 0's JSON line passes through.  Under an existing launcher
+(WORLD_SIZE set) `--gpus` must equal WORLD_SIZE.
+
+Workloads
+  cfg2 (default; the configuration the BASELINE metric is quoted on), weak scaling: per GPU,
+       DANCE R50 snake head, fp32, 16 images x 100 instances x 128 vertices on synthetic
+       800x1216 FPN features (16, 1+256, 200, 304), attention + individual scale, 3 iterations.
+  cfg3 the same at 32 images per GPU.
+  cfg5 strong scaling: ONE fixed sweep of 256 images x 300 instances x 256 vertices; rank r
+       holds and deforms the images `distributed.image_range(256, r, world)`, then every rank
+       receives the whole deformed set (counts all-gather + padded RCCL all-gather).
+One step = the reference's `snake_deformation` scope (snake_head.py:1822-1862) over the rank's
 batch, starting from the NCHW (attention + features) tensor resident in HBM: layout pass,
 3 x (fused gather + head block, 7 residual blocks, fusion + max, prediction, offset
 update) and, for N > 1, the RCCL all-gather of the deformed contours.
@@ -17,6 +28,8 @@ Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for every field.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +48,12 @@ GATHER_BYTES_PER_VERTEX = 4 * (CH + 1) * 4            # 4 taps x 257 channels x 
 PEAK_F32_MFMA_TFLOPS = 157.3                          # MI355X_MICROARCH.md, f32-input MFMA
 PEAK_F16_MFMA_TFLOPS = 2500.0                         # MI355X_MICROARCH.md, BF16/FP16 dense
 PEAK_HBM_GBPS = 8000.0
+# images (per GPU when weak, in total when strong), instances per image, vertices, scaling
+WORKLOADS = {"cfg2": (16, 100, 128, "weak"), "cfg3": (32, 100, 128, "weak"), "cfg5": (256, 300, 256, "strong")}
+WORKLOAD_NAMES = {"cfg2": "BASELINE config 2", "cfg3": "BASELINE config 3", "cfg5": "BASELINE config 5"}
+# contours per kernel sequence above which a rank's batch is deformed in chunks (workspace:
+# 0.83 MB per 128-vertex contour, 1.65 MB per 256-vertex one)
+CHUNK_CAP = 9600
 
 
 def measured_traffic(kernel, workgroups):
@@ -53,14 +72,19 @@ def measured_traffic(kernel, workgroups):
     return None, None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=IMAGES, help="images per GPU")
-    ap.add_argument("--per-image", type=int, default=PER_IMAGE)
-    ap.add_argument("--vertices", type=int, default=VERTS)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--images", type=int, default=None,
+                    help="images per GPU (weak workloads) / in the whole sweep (cfg5)")
+    ap.add_argument("--per-image", type=int, default=None)
+    ap.add_argument("--vertices", type=int, default=None)
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher / shard / all-gather rehearsal on the CPU (gloo, a stub in place of the "
+                         "HIP deformer, tiny sizes); prints a line marked dry_run, never a measurement")
     ap.add_argument("--layout", choices=("nchw", "nhwc"), default="nchw",
                     help="nchw (default): the layout pass is inside the timed step")
     ap.add_argument("--no-fused-head", action="store_true")
@@ -74,9 +98,79 @@ def parse():
                          "events then; measured -4 %% wall with 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-feat-prep", action="store_true", help="skip the untimed bottom_out measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip every untimed extra (two streams, feature prep, attender, RLE, FCOSE decode)")
     ap.add_argument("--cpu-reps", type=int, default=40,
                     help="timed oracle runs of config 1 (about 10 s of CPU work in total)")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    b, per, v, scaling = WORKLOADS[args.workload]
+    args.images = b if args.images is None else args.images
+    args.per_image = per if args.per_image is None else args.per_image
+    args.vertices = v if args.vertices is None else args.vertices
+    args.scaling = scaling
+    return args
+
+
+def launch_ranks(args, argv):
+    """Start `args.gpus` ranks of this script, one process per GPU, and exit with their status.
+    Counterpart of the reference's own launcher (train_net.py:76-83).  The parent touches no GPU
+    (torch.cuda.device_count() does not initialise one) and replaces no process: the launcher is
+    a child, its stdout (rank 0's JSON line) and stderr are inherited."""
+    if not args.dry_run_cpu:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 1) // args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def dry_run_cpu(args, rank, world):
+    """The multi-rank plumbing of this script -- launcher, by-image shard, counts + contour
+    all-gather, max-over-ranks timing, one JSON line -- on the CPU with gloo and a stub in place
+    of the HIP deformer (every vertex moves by (image + 1, 2 * image + 1)), at toy sizes."""
+    from dance_amd.distributed import ImageShard, all_gather_contours, gather_shards
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    b, v = 8, 8
+    per = [1 + (i * 5) % 4 for i in range(b)]                     # ragged instances per image
+    if args.scaling == "weak":
+        per = [3] * b
+    n = sum(per)
+    g = torch.Generator().manual_seed(7)
+    full = torch.rand((n, v, 2), generator=g) * 100
+    image_idx = torch.repeat_interleave(torch.arange(b), torch.tensor(per)).float()
+
+    def stub(c, idx):
+        return c + torch.stack([idx + 1, 2 * idx + 1], 1)[:, None, :]
+
+    if args.scaling == "strong":
+        shard = ImageShard(image_idx, b, rank, world)
+        lo = shard.images[0]
+        out = gather_shards(stub(shard.take(full), shard.local_image_idx + lo))
+        want = stub(full, image_idx)
+    else:
+        out = all_gather_contours(stub(full + rank, image_idx))
+        want = torch.cat([stub(full + r, image_idx) for r in range(world)])
+    ok = torch.equal(out, want)
+    t = torch.tensor([float(ok)])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "DRY RUN on the CPU (gloo, stub deformer): not a measurement",
+                          "n_gpus": world, "gpus_flag": args.gpus, "scaling": args.scaling,
+                          "contours": int(out.size(0)), "ok": bool(t.item() == 1.0)}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if t.item() == 1.0 else 1
 
 
 def cpu_baseline(reps):
@@ -110,52 +204,85 @@ def cpu_baseline(reps):
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, argv)                                 # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.dry_run_cpu:
+        sys.exit(dry_run_cpu(args, rank, world))
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from dance_amd import config, modules, ops, snake, synthetic
     from dance_amd._lib import EVOLVE_EVENTS, STAGE_NAMES
-    from dance_amd.distributed import all_gather_contours
+    from dance_amd.distributed import ImageShard, all_gather_contours, gather_shards
 
-    b, per, v = args.images, args.per_image, args.vertices
-    n = b * per
+    per, v = args.per_image, args.vertices
     h, w = HF * 4, WF * 4
+    strong = args.scaling == "strong"
+    if strong:
+        # ONE sweep of args.images images for the whole job; this rank holds a block of them
+        b_total = args.images
+        n_total = b_total * per
+        boxes_all = synthetic.make_boxes(n_total, h, w, 4321)
+        idx_all = torch.arange(b_total).repeat_interleave(per).float()
+        shard = ImageShard(idx_all, b_total, rank, world)
+        img_lo, img_hi = shard.images
+        b = img_hi - img_lo
+        boxes = shard.take(boxes_all)
+        image_idx = shard.local_image_idx.to(dev)
+        del boxes_all, idx_all
+    else:
+        b = args.images
+        n_total = world * b * per
+        boxes = synthetic.make_boxes(b * per, h, w, 4321 + rank)
+        image_idx = torch.arange(b).repeat_interleave(per).float().to(dev)
+    n = boxes.size(0)
     cfg = config.dance_r50(num_sampling=v, num_convs=0)
     sd = {k: t.clone() for k, t in modules.RefineNet(cfg).state_dict().items()}
     synthetic.fill_state_dict_(sd, 1234)
     nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), dev) for i in range(ITERS)]
     deformer = snake.ContourDeformer(nets, fused_head=not args.no_fused_head, precision=args.precision)
-    deformer.MAX_CHUNK = max(deformer.MAX_CHUNK, n)          # one kernel sequence per iteration
+    # one kernel sequence per iteration up to CHUNK_CAP contours, chunks of CHUNK_CAP beyond
+    single_chunk = n <= CHUNK_CAP
+    deformer.MAX_CHUNK = n if single_chunk else CHUNK_CAP
+    n_ev = min(n, CHUNK_CAP)                                  # contours of the launches the events time
 
     # synthetic inputs, resident in HBM before the timed region
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     feats = torch.empty((b, CH + 1, HF, WF), dtype=torch.float32, device=dev)
-    for i in range(b):                                       # per image: bounds host memory
-        feats[i] = synthetic.make_features(1, CH, HF, WF, 1234 + 1000 * rank + i)[0].to(dev)
-    boxes = synthetic.make_boxes(n, h, w, 4321 + rank)
+    if strong:
+        # drawn on the device from the GLOBAL image number: a rank's images do not depend on the split
+        for i in range(b):
+            g = torch.Generator(device=dev).manual_seed(1234 + img_lo + i)
+            feats[i].normal_(generator=g)
+            feats[i, 0].uniform_(generator=g)
+    else:
+        for i in range(b):                                   # per image: bounds host memory
+            feats[i] = synthetic.make_features(1, CH, HF, WF, 1234 + 1000 * rank + i)[0].to(dev)
     whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).to(dev)
     init, _ = ops.uniform_upsample(boxes.to(dev), v, kind=ops.POLY_BOX)
-    image_idx = torch.arange(b).repeat_interleave(per).float().to(dev)
     sizes = [(h, w)] * b
-    del g
 
     # Timed steps carry three events per iteration only (an event record costs ~4 us of stream
     # time): before the head kernel, after it, after the last residual block -- the gather
     # figure and the roofline of the dominant kernel.  The full per-stage breakdown comes from
-    # an instrumented pass after the timed region.
+    # an instrumented pass after the timed region.  A batch deformed in chunks (n > CHUNK_CAP)
+    # carries no events in the timed steps; the instrumented pass runs its first chunk.
     TIMED = (0, 1, 8)
     events = [[[torch.cuda.Event(enable_timing=True) if i in TIMED else None for i in range(EVOLVE_EVENTS)]
-               for _ in range(ITERS)] for _ in range(args.steps)]
+               for _ in range(ITERS)] for _ in range(args.steps)] if single_chunk else None
     events_full = [[[torch.cuda.Event(enable_timing=True) for _ in range(EVOLVE_EVENTS)]
                     for _ in range(ITERS)] for _ in range(args.steps)]
-    for step_ev in events + events_full:
+    for step_ev in (events or []) + events_full:
         for it_ev in step_ev:
             for e in it_ev:
                 if e is not None:
@@ -175,7 +302,8 @@ def main():
             f = pre
         preds = deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc",
                                 stage_events=ev if args.streams == 1 else None, streams=args.streams)
-        return all_gather_contours(preds[-1])
+        # the path's one exchange step: every rank receives all deformed contours
+        return gather_shards(preds[-1]) if strong else all_gather_contours(preds[-1])
 
     for _ in range(args.warmup):
         out = step()
@@ -185,7 +313,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        out = step(events[k], layout_ev[k])
+        out = step(events[k] if events else None, layout_ev[k])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -195,22 +323,26 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert out.shape == (world * n, v, 2) and bool(torch.isfinite(out).all())
+    assert out.shape == (n_total, v, 2) and bool(torch.isfinite(out).all())
+    mine = out[shard.index.to(dev)] if strong else out[rank * n:(rank + 1) * n]   # this rank's rows of the gathered set
     if rank == 0:
-        # instrumented single-stream pass (every stage boundary); with --streams > 1 it also
-        # supplies the three timed events, which cannot be read off overlapping streams
+        # instrumented single-stream pass (every stage boundary) over the first chunk; with
+        # --streams > 1 or a chunked batch it also supplies the three timed events
         for k in range(args.steps):
             f = deformer.prepare_features(feats) if pre is None else pre
-            deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", stage_events=events_full[k])
+            deformer.deform(f, init[:n_ev], image_idx[:n_ev], sizes, whs[:n_ev], layout="nhwc",
+                            stage_events=events_full[k])
         torch.cuda.synchronize()
-        if args.streams > 1:
+        if args.streams > 1 or events is None:
             events = events_full
 
     # the same steps with the contours split over two HIP streams (bit-identical results; one
     # half's kernel tails and launch gaps overlap the other half's kernels).  Reported beside
     # the headline, never as it: per-kernel event timing is only meaningful on one stream.
     two_streams = None
-    if rank == 0 and world == 1 and args.streams == 1:
+    # the untimed extras (stages either side of the path) run at the one-GPU weak workloads only
+    extras = rank == 0 and not strong and b <= 32 and not args.no_extras
+    if extras and world == 1 and args.streams == 1:
         def step2():
             f = deformer.prepare_features(feats) if pre is None else pre
             return deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", streams=2)[-1]
@@ -222,7 +354,7 @@ def main():
             out2 = step2()
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t2
-        assert torch.equal(out2, out[:n]), "two-stream deformation differs from the single-stream one"
+        assert torch.equal(out2, mine), "two-stream deformation differs from the single-stream one"
         two_streams = {"value": n * args.steps / dt2, "unit": "contours/s", "ms_per_step": dt2 / args.steps * 1e3,
                        "note": "deform(..., streams=2) / DANCE_STREAMS=2, same steps, results bit-identical"}
 
@@ -233,11 +365,11 @@ def main():
         f_nhwc, att_plane = deformer.prepare_features(feats) if pre is None else pre
         idx32 = image_idx.to(torch.int32)
         for _ in range(2):
-            ops.gather_features(f_nhwc, att_plane, init, idx32, ops.PAD_REFLECTION, "derange")
+            ops.gather_features(f_nhwc, att_plane, init[:n_ev], idx32[:n_ev], ops.PAD_REFLECTION, "derange")
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
         for _ in range(10):
-            ops.gather_features(f_nhwc, att_plane, init, idx32, ops.PAD_REFLECTION, "derange")
+            ops.gather_features(f_nhwc, att_plane, init[:n_ev], idx32[:n_ev], ops.PAD_REFLECTION, "derange")
         g1.record()
         torch.cuda.synchronize()
         gather_alone_ms = g0.elapsed_time(g1) / 10
@@ -254,8 +386,8 @@ def main():
         sampling_ms = g0.elapsed_time(g1) / 10
         # the reference's `snake_feat_prep` scope (snake_head.py:1816-1820): bottom_out =
         # 2 x [conv3x3 256->256 + GroupNorm(32) + ReLU] on the same maps, HIP path vs stock torch.nn
-        feat_prep = None
-        if not args.no_feat_prep:
+        feat_prep = mask_rle = attender_fig = fcose_fig = None
+        if extras and not args.no_feat_prep:
             cfg2 = config.dance_r50(num_sampling=v, num_convs=2)
             net2 = modules.RefineNet(cfg2)
             sd2 = {k: t.clone() for k, t in net2.state_dict().items()}
@@ -296,144 +428,145 @@ def main():
                          "frac_of_f16_peak": 3 * fp_flops / hip_ms / 1e9 / PEAK_F16_MFMA_TFLOPS,
                          "stock_torch_ms": stock_ms, "speedup_vs_stock": stock_ms / hip_ms}
             del net2, layers
-        # the attention-map producer in front of the path: EdgeSnakeFPNHead.attender
-        # (edge_det.py:66-100, 200-204) on the batch's (b,1,200,304) edge maps, HIP vs stock torch.nn
-        att_mod = modules.Attender()
-        sd_a = {k: t.clone() for k, t in att_mod.state_dict().items()}
-        synthetic.fill_state_dict_(sd_a, 1234)
-        att_mod.load_state_dict(sd_a)
-        att_mod = att_mod.to(dev).eval()
-        edge_in = (1 - feats[:, :1]).contiguous()
+        if extras:
+            # the attention-map producer in front of the path: EdgeSnakeFPNHead.attender
+            # (edge_det.py:66-100, 200-204) on the batch's (b,1,200,304) edge maps, HIP vs stock torch.nn
+            att_mod = modules.Attender()
+            sd_a = {k: t.clone() for k, t in att_mod.state_dict().items()}
+            synthetic.fill_state_dict_(sd_a, 1234)
+            att_mod.load_state_dict(sd_a)
+            att_mod = att_mod.to(dev).eval()
+            edge_in = (1 - feats[:, :1]).contiguous()
 
-        def stock_att():
-            x = edge_in
-            for i in (0, 1):
-                x = torch.relu(torch.nn.functional.group_norm(
-                    torch.nn.functional.conv2d(x, att_mod[i].weight, None, padding=1), 4,
-                    att_mod[i].norm.weight, att_mod[i].norm.bias, 1e-5))
-            return torch.sigmoid(torch.nn.functional.conv2d(x, att_mod[2].weight, att_mod[2].bias, padding=1))
+            def stock_att():
+                x = edge_in
+                for i in (0, 1):
+                    x = torch.relu(torch.nn.functional.group_norm(
+                        torch.nn.functional.conv2d(x, att_mod[i].weight, None, padding=1), 4,
+                        att_mod[i].norm.weight, att_mod[i].norm.bias, 1e-5))
+                return torch.sigmoid(torch.nn.functional.conv2d(x, att_mod[2].weight, att_mod[2].bias, padding=1))
 
-        def timed2(fn, reps):
-            for _ in range(2):
+            def timed2(fn, reps):
+                for _ in range(2):
+                    fn()
+                g0.record()
+                for _ in range(reps):
+                    fn()
+                g1.record()
+                torch.cuda.synchronize()
+                return g0.elapsed_time(g1) / reps
+
+            with torch.no_grad():
+                att_ms, att_stock_ms = timed2(lambda: att_mod(edge_in), 10), timed2(stock_att, 5)
+                att_err = float((att_mod(edge_in) - stock_att()).abs().max())
+            attender_fig = {"stage": "attender: 3 x conv3x3 (1->32->32->1) + 2 x GroupNorm(4,32) + ReLU + sigmoid on "
+                                     "(%d,1,%d,%d); outside the timed step" % (b, HF, WF),
+                            "kernel": "k_att_stats1 + k_att_conv2 + k_att_out (fp32 FMA)", "ms": att_ms,
+                            "algorithmic_TFLOPs": 2.0 * (288 + 9216 + 288) * HF * WF * b / att_ms / 1e9,
+                            "stock_torch_ms": att_stock_ms, "speedup_vs_stock": att_stock_ms / att_ms,
+                            "max_abs_diff_vs_stock": att_err}
+            del att_mod
+
+            # the step after the path: deformed contours -> RLE masks, the
+            # reference's get_polygon_rles (coco_evaluation.py:311-318; one pycocotools call per
+            # instance on the host there).  Contours clipped to the image as postprocessing does.
+            from dance_amd import rle
+
+            def time_rle(polys):
+                for _ in range(2):
+                    r = rle.polygon_rle(polys, (h, w))
+                cap = r.counts.size(1)                            # settled capacity: one launch per call
+                g0.record()
+                for _ in range(10):
+                    r = rle.polygon_rle(polys, (h, w), cap=cap)
+                g1.record()
+                torch.cuda.synchronize()
+                ms = g0.elapsed_time(g1) / 10
+                t0 = time.perf_counter()
+                strings = r.strings()
+                return r, strings, {"ms": ms, "polygons_per_s": n / (ms * 1e-3), "mean_runs": float(r.m.float().mean()),
+                                    "strings_ms_incl_d2h": (time.perf_counter() - t0) * 1e3}
+
+            ellipses = synthetic.make_circle_contours(boxes, v).to(dev)
+            polys = mine.clone()
+            polys[..., 0].clamp_(0, w)
+            polys[..., 1].clamp_(0, h)
+            r, strings, fig = time_rle(ellipses)
+            _, _, fig_jagged = time_rle(polys)
+            mask_rle = dict({"stage": "polygon -> RLE of %d %d-vertex contours at %dx%d (k_polygon_rle, one workgroup per "
+                                      "polygon, parity bitmap in LDS); outside the timed step" % (n, v, h, w),
+                             "contours": "ellipses inscribed in the synthetic boxes (radius 20-100 px)"}, **fig)
+            mask_rle["deformed_contours"] = dict(fig_jagged, note="the bench's own output: white-noise features make "
+                                                 "these contours jagged (perimeters of ~10^4 px), a stress case")
+            mask_rle["note"] = "includes the wrapper's capacity check (one device sync per call)"
+            polys = ellipses
+            if not args.no_cpu_baseline:
+                from oracle import rle_ref
+                sample = polys[:200].cpu().numpy()
+                t0 = time.perf_counter()
+                ref_strings = [rle_ref.to_string(rle_ref.fr_poly(p_, h, w)) for p_ in sample]
+                dt = time.perf_counter() - t0
+                assert ref_strings == strings[:200], "bench: RLE strings differ from the oracle"
+                mask_rle["cpu_oracle"] = {"polygons_per_s": 200 / dt, "cores": 1, "kind": "port",
+                                          "sample": "first 200 of the same contours, oracle/rle_ref.c through ctypes"}
+
+            # the producer of the boxes: FCOSE decode of the detector head's outputs,
+            # forward_for_single_feature_map of every level and image (fcose_outputs.py:444-521), before NMS
+            from dance_amd import fcose_outputs
+            fc_shapes, fc_strides, fc_c, fc_th = [(100, 152), (50, 76), (25, 38), (13, 19), (7, 10)], [8, 16, 32, 64, 128], 80, 0.05
+            gg = torch.Generator(device=dev).manual_seed(77)
+            fc_logits = [torch.randn(b, fc_c, hh, ww, generator=gg, device=dev) * 1.5 - 6.5 for hh, ww in fc_shapes]
+            fc_ctr = [torch.randn(b, 1, hh, ww, generator=gg, device=dev) for hh, ww in fc_shapes]
+            fc_reg = [torch.rand(b, 4, hh, ww, generator=gg, device=dev) * 6 + 0.25 for hh, ww in fc_shapes]
+            fc_ext = [torch.randn(b, 4, hh, ww, generator=gg, device=dev) * 0.3 for hh, ww in fc_shapes]
+            fc_loc = fcose_outputs.compute_locations(fc_logits, fc_strides)
+
+            def fc_hip():
+                return fcose_outputs.decode_candidates(fc_loc, fc_logits, fc_reg, fc_ext, fc_ctr, fc_strides, fc_th, True)
+
+            def fc_stock():
+                # the reference's op sequence with stock torch ops (per level: permute, sigmoid, mask;
+                # per image: nonzero, gathers, stack, sqrt)
+                n_out = 0
+                for l, (hh, ww) in enumerate(fc_shapes):
+                    cls = fc_logits[l].permute(0, 2, 3, 1).reshape(b, -1, fc_c).sigmoid()
+                    regl = (fc_reg[l] * fc_strides[l]).permute(0, 2, 3, 1).reshape(b, -1, 4)
+                    extl = fc_ext[l].permute(0, 2, 3, 1).reshape(b, -1, 4)
+                    cls = cls * fc_ctr[l].permute(0, 2, 3, 1).reshape(b, -1).sigmoid()[:, :, None]
+                    cand = cls > fc_th
+                    for i in range(b):
+                        nz = cand[i].nonzero()
+                        pl, r, e = fc_loc[l][nz[:, 0]], regl[i][nz[:, 0]], extl[i][nz[:, 0]]
+                        det = torch.stack([pl[:, 0] - r[:, 0], pl[:, 1] - r[:, 1], pl[:, 0] + r[:, 2], pl[:, 1] + r[:, 3]], 1)
+                        bw, bh = det[:, 2] - det[:, 0], det[:, 3] - det[:, 1]
+                        torch.stack([pl[:, 0] + bw * e[:, 0], det[:, 1], det[:, 0], pl[:, 1] + bh * e[:, 1],
+                                     pl[:, 0] + bw * e[:, 2], det[:, 3], det[:, 2], pl[:, 1] + bh * e[:, 3]], 1)
+                        torch.sqrt(cls[i][cand[i]])
+                        n_out += nz.size(0)
+                return n_out
+
+            def wall_ms(fn, reps):
                 fn()
-            g0.record()
-            for _ in range(reps):
-                fn()
-            g1.record()
-            torch.cuda.synchronize()
-            return g0.elapsed_time(g1) / reps
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    r_ = fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) * 1e3 / reps, r_
 
-        with torch.no_grad():
-            att_ms, att_stock_ms = timed2(lambda: att_mod(edge_in), 10), timed2(stock_att, 5)
-            att_err = float((att_mod(edge_in) - stock_att()).abs().max())
-        attender_fig = {"stage": "attender: 3 x conv3x3 (1->32->32->1) + 2 x GroupNorm(4,32) + ReLU + sigmoid on "
-                                 "(%d,1,%d,%d); outside the timed step" % (b, HF, WF),
-                        "kernel": "k_att_stats1 + k_att_conv2 + k_att_out (fp32 FMA)", "ms": att_ms,
-                        "algorithmic_TFLOPs": 2.0 * (288 + 9216 + 288) * HF * WF * b / att_ms / 1e9,
-                        "stock_torch_ms": att_stock_ms, "speedup_vs_stock": att_stock_ms / att_ms,
-                        "max_abs_diff_vs_stock": att_err}
-        del att_mod
-
-        # the step after the path: deformed contours -> RLE masks, the
-        # reference's get_polygon_rles (coco_evaluation.py:311-318; one pycocotools call per
-        # instance on the host there).  Contours clipped to the image as postprocessing does.
-        from dance_amd import rle
-
-        def time_rle(polys):
-            for _ in range(2):
-                r = rle.polygon_rle(polys, (h, w))
-            cap = r.counts.size(1)                            # settled capacity: one launch per call
-            g0.record()
-            for _ in range(10):
-                r = rle.polygon_rle(polys, (h, w), cap=cap)
-            g1.record()
-            torch.cuda.synchronize()
-            ms = g0.elapsed_time(g1) / 10
-            t0 = time.perf_counter()
-            strings = r.strings()
-            return r, strings, {"ms": ms, "polygons_per_s": n / (ms * 1e-3), "mean_runs": float(r.m.float().mean()),
-                                "strings_ms_incl_d2h": (time.perf_counter() - t0) * 1e3}
-
-        ellipses = synthetic.make_circle_contours(boxes, v).to(dev)
-        polys = out[:n].clone()
-        polys[..., 0].clamp_(0, w)
-        polys[..., 1].clamp_(0, h)
-        r, strings, fig = time_rle(ellipses)
-        _, _, fig_jagged = time_rle(polys)
-        mask_rle = dict({"stage": "polygon -> RLE of %d %d-vertex contours at %dx%d (k_polygon_rle, one workgroup per "
-                                  "polygon, parity bitmap in LDS); outside the timed step" % (n, v, h, w),
-                         "contours": "ellipses inscribed in the synthetic boxes (radius 20-100 px)"}, **fig)
-        mask_rle["deformed_contours"] = dict(fig_jagged, note="the bench's own output: white-noise features make "
-                                             "these contours jagged (perimeters of ~10^4 px), a stress case")
-        mask_rle["note"] = "includes the wrapper's capacity check (one device sync per call)"
-        polys = ellipses
-        if not args.no_cpu_baseline:
-            from oracle import rle_ref
-            sample = polys[:200].cpu().numpy()
-            t0 = time.perf_counter()
-            ref_strings = [rle_ref.to_string(rle_ref.fr_poly(p_, h, w)) for p_ in sample]
-            dt = time.perf_counter() - t0
-            assert ref_strings == strings[:200], "bench: RLE strings differ from the oracle"
-            mask_rle["cpu_oracle"] = {"polygons_per_s": 200 / dt, "cores": 1, "kind": "port",
-                                      "sample": "first 200 of the same contours, oracle/rle_ref.c through ctypes"}
-
-        # the producer of the boxes: FCOSE decode of the detector head's outputs,
-        # forward_for_single_feature_map of every level and image (fcose_outputs.py:444-521), before NMS
-        from dance_amd import fcose_outputs
-        fc_shapes, fc_strides, fc_c, fc_th = [(100, 152), (50, 76), (25, 38), (13, 19), (7, 10)], [8, 16, 32, 64, 128], 80, 0.05
-        gg = torch.Generator(device=dev).manual_seed(77)
-        fc_logits = [torch.randn(b, fc_c, hh, ww, generator=gg, device=dev) * 1.5 - 6.5 for hh, ww in fc_shapes]
-        fc_ctr = [torch.randn(b, 1, hh, ww, generator=gg, device=dev) for hh, ww in fc_shapes]
-        fc_reg = [torch.rand(b, 4, hh, ww, generator=gg, device=dev) * 6 + 0.25 for hh, ww in fc_shapes]
-        fc_ext = [torch.randn(b, 4, hh, ww, generator=gg, device=dev) * 0.3 for hh, ww in fc_shapes]
-        fc_loc = fcose_outputs.compute_locations(fc_logits, fc_strides)
-
-        def fc_hip():
-            return fcose_outputs.decode_candidates(fc_loc, fc_logits, fc_reg, fc_ext, fc_ctr, fc_strides, fc_th, True)
-
-        def fc_stock():
-            # the reference's op sequence with stock torch ops (per level: permute, sigmoid, mask;
-            # per image: nonzero, gathers, stack, sqrt)
-            n_out = 0
-            for l, (hh, ww) in enumerate(fc_shapes):
-                cls = fc_logits[l].permute(0, 2, 3, 1).reshape(b, -1, fc_c).sigmoid()
-                regl = (fc_reg[l] * fc_strides[l]).permute(0, 2, 3, 1).reshape(b, -1, 4)
-                extl = fc_ext[l].permute(0, 2, 3, 1).reshape(b, -1, 4)
-                cls = cls * fc_ctr[l].permute(0, 2, 3, 1).reshape(b, -1).sigmoid()[:, :, None]
-                cand = cls > fc_th
-                for i in range(b):
-                    nz = cand[i].nonzero()
-                    pl, r, e = fc_loc[l][nz[:, 0]], regl[i][nz[:, 0]], extl[i][nz[:, 0]]
-                    det = torch.stack([pl[:, 0] - r[:, 0], pl[:, 1] - r[:, 1], pl[:, 0] + r[:, 2], pl[:, 1] + r[:, 3]], 1)
-                    bw, bh = det[:, 2] - det[:, 0], det[:, 3] - det[:, 1]
-                    torch.stack([pl[:, 0] + bw * e[:, 0], det[:, 1], det[:, 0], pl[:, 1] + bh * e[:, 1],
-                                 pl[:, 0] + bw * e[:, 2], det[:, 3], det[:, 2], pl[:, 1] + bh * e[:, 3]], 1)
-                    torch.sqrt(cls[i][cand[i]])
-                    n_out += nz.size(0)
-            return n_out
-
-        def wall_ms(fn, reps):
-            fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                r_ = fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) * 1e3 / reps, r_
-
-        fc_ms, (fc_fields, _) = wall_ms(fc_hip, 10)
-        fc_stock_ms, fc_n = wall_ms(fc_stock, 3)
-        fc_bytes = sum(b * (fc_c + 9) * hh * ww * 4 for hh, ww in fc_shapes)
-        fcose_fig = {"stage": "FCOSE decode of %d images x 5 levels (800x1216) x %d classes: sigmoid scores x centerness, "
-                              "threshold %.2f, compaction in `nonzero` order, box + extreme-point decode; outside the "
-                              "timed step" % (b, fc_c, fc_th),
-                     "kernel": "k_fcose_count + torch.cumsum + k_fcose_fill (one launch each for all levels)", "candidates": int(
-                         fc_fields["scores"].numel()), "ms_wall_incl_one_sync": fc_ms,
-                     "algorithmic_GBps": fc_bytes / fc_ms / 1e6, "stock_torch_ms": fc_stock_ms,
-                     "speedup_vs_stock": fc_stock_ms / fc_ms, "stock_candidates": fc_n,
-                     "note": "host-inclusive wall time (the decode ends in one device -> host copy of the segment "
-                             "bounds; the stock sequence syncs once per image and level in nonzero())"}
-        del fc_logits, fc_ctr, fc_reg, fc_ext, fc_fields
+            fc_ms, (fc_fields, _) = wall_ms(fc_hip, 10)
+            fc_stock_ms, fc_n = wall_ms(fc_stock, 3)
+            fc_bytes = sum(b * (fc_c + 9) * hh * ww * 4 for hh, ww in fc_shapes)
+            fcose_fig = {"stage": "FCOSE decode of %d images x 5 levels (800x1216) x %d classes: sigmoid scores x centerness, "
+                                  "threshold %.2f, compaction in `nonzero` order, box + extreme-point decode; outside the "
+                                  "timed step" % (b, fc_c, fc_th),
+                         "kernel": "k_fcose_count + torch.cumsum + k_fcose_fill (one launch each for all levels)", "candidates": int(
+                             fc_fields["scores"].numel()), "ms_wall_incl_one_sync": fc_ms,
+                         "algorithmic_GBps": fc_bytes / fc_ms / 1e6, "stock_torch_ms": fc_stock_ms,
+                         "speedup_vs_stock": fc_stock_ms / fc_ms, "stock_candidates": fc_n,
+                         "note": "host-inclusive wall time (the decode ends in one device -> host copy of the segment "
+                                 "bounds; the stock sequence syncs once per image and level in nonzero())"}
+            del fc_logits, fc_ctr, fc_reg, fc_ext, fc_fields
 
     if rank == 0:
         # per-stage device time from the HIP events recorded inside the timed steps
@@ -459,21 +592,24 @@ def main():
             head_ms = head_ms + res7_ms                         # the fused launch
             macs_dom = (CH + 2) * 128 * 9 + 7 * MACS_RES_BLOCK
             res_ms = head_ms
-            res_tflops = 2.0 * macs_dom * v * n / (res_ms * 1e-3) / 1e12        # algorithmic
+            res_tflops = 2.0 * macs_dom * v * n_ev / (res_ms * 1e-3) / 1e12     # algorithmic
         else:
             res_ms = res7_ms / 7.0                              # per residual block
-            res_tflops = 2.0 * MACS_RES_BLOCK * v * n / (res_ms * 1e-3) / 1e12  # algorithmic
-        gather_gbps = GATHER_BYTES_PER_VERTEX * v * n / (head_ms * 1e-3) / 1e9
+            res_tflops = 2.0 * MACS_RES_BLOCK * v * n_ev / (res_ms * 1e-3) / 1e12  # algorithmic
+        gather_gbps = GATHER_BYTES_PER_VERTEX * v * n_ev / (head_ms * 1e-3) / 1e9
         layout_ms = (sum(a.elapsed_time(b_) for a, b_ in layout_ev) / args.steps) if pre is None else 0.0
         ms_per_step = elapsed / args.steps * 1e3
-        total_flops = 2.0 * MACS_PER_VERTEX * v * n * ITERS
+        total_flops = 2.0 * MACS_PER_VERTEX * v * n_total * ITERS     # whole job
         rt = 2 if v <= 64 else 4 if v <= 128 else 7 if v <= 224 else 8
         # dance_res_stack16's dispatch: 8-wave kernel above 128 vertices and for few long rings
-        stack_wide = v > 128 or (v > 96 and n <= int(os.environ.get("DANCE_STACK_SMALL_N", "256")))
+        stack_wide = v > 128 or (v > 96 and n_ev <= int(os.environ.get("DANCE_STACK_SMALL_N", "256")))
         if args.precision in ("fp16x3", "fp16"):
             terms = 3 if args.precision == "fp16x3" else 1
             # every algorithmic product is three f16 MFMA products (A_lo*B_hi + A_hi*B_lo +
-            # A_hi*B_hi); the roofline prices the EXECUTED f16 MFMA flops against the f16 peak
+            # A_hi*B_hi).  `achieved` / `frac` price the ALGORITHMIC flops (SURVEY 8d's figure) against
+            # the f16 dense peak; `frac_executed` counts the three MFMAs each product costs (the pipe
+            # utilisation); `frac_vs_f32_mfma_peak` is the same useful rate against the fp32-MFMA peak
+            # that the reference's own fp32 arithmetic would be limited to
             kname = ("k_head_stack16s<%d,%d> (gather + head SnakeBlock 258->128 + the 7 residual SnakeBlocks "
                      "128->128, k=9, in one launch; %s f16 MFMA)" if head_stack else
                      ("k_res_stack16w" if stack_wide else "k_res_stack16s") +
@@ -484,20 +620,27 @@ def main():
             kname = kname % ((rt, terms, "split-half" if terms == 3 else "single-term") if stacked else
                              ("s" if rt <= 4 else "", rt, terms, "split-half" if terms == 3 else "single-term"))
             roof = {"kernel": kname,
-                    "bound": "mfma", "achieved": terms * res_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": terms * res_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                    "bound": "mfma", "achieved": res_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": res_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                    "frac_algorithmic": res_tflops / PEAK_F16_MFMA_TFLOPS,
+                    "achieved_executed": terms * res_tflops,
+                    "frac_executed": terms * res_tflops / PEAK_F16_MFMA_TFLOPS,
+                    "frac_vs_f32_mfma_peak": res_tflops / PEAK_F32_MFMA_TFLOPS,
                     "avg_launch_ms": res_ms if head_stack else res7_ms if stacked else res_ms,
-                    "algorithmic_GFLOP_per_launch": (2.0 * macs_dom * v * n / 1e9 if head_stack else
-                                                     2.0 * MACS_RES_BLOCK * v * n * (7 if stacked else 1) / 1e9),
+                    "algorithmic_GFLOP_per_launch": (2.0 * macs_dom * v * n_ev / 1e9 if head_stack else
+                                                     2.0 * MACS_RES_BLOCK * v * n_ev * (7 if stacked else 1) / 1e9),
                     "algorithmic_TFLOPs": res_tflops, "mfma_per_product": terms,
-                    "note": "achieved = executed f16 MFMA flops (%d x algorithmic) / spacing of the two HIP events "
-                            "around the residual blocks in the timed steps (event spacing includes the "
-                            "inter-kernel gap, ~10 us per launch)" % terms}
+                    "contours_per_launch": n_ev,
+                    "note": "achieved = algorithmic flops per launch / spacing of the two HIP events around the "
+                            "residual blocks (event spacing includes the inter-kernel gap, ~10 us per launch), "
+                            + ("recorded inside the timed steps" if single_chunk and args.streams == 1 else
+                               "recorded in an instrumented pass over the first %d contours after the timed "
+                               "region" % n_ev) + "; executed = %d f16 MFMAs per product" % terms}
             if terms == 3:
                 roof["traffic"], roof["traffic_source"] = measured_traffic(
                     "k_head_stack16s" if head_stack else ("k_res_stack16w" if stack_wide else "k_res_stack16s")
                     if stacked else
-                    "k_conv16s" if rt <= 4 else "k_conv16<", n)
+                    "k_conv16s" if rt <= 4 else "k_conv16<", n_ev)
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"
             gkernel = ("k_head_stack16s<%d> (fused gather + head SnakeBlock + residual stack)" % rt if head_stack
                        else "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt)
@@ -505,21 +648,30 @@ def main():
             roof = {"kernel": "k_circconv<%d> (residual SnakeBlock 128->128, k=9, f32 MFMA)" % rt,
                     "bound": "mfma", "achieved": res_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": res_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                    "avg_launch_ms": res_ms, "algorithmic_TFLOPs": res_tflops, "mfma_per_product": 1}
+                    "frac_algorithmic": res_tflops / PEAK_F32_MFMA_TFLOPS,
+                    "frac_executed": res_tflops / PEAK_F32_MFMA_TFLOPS,
+                    "avg_launch_ms": res_ms, "algorithmic_TFLOPs": res_tflops, "mfma_per_product": 1,
+                    "contours_per_launch": n_ev}
             dtype = "f32"
             gkernel = "k_gather_head<%d> (fused gather + head SnakeBlock)" % rt
         line = {
-            "metric": "contours deformed/sec (128 vertices, all iters)",
-            "value": world * n * args.steps / elapsed,
+            "metric": "contours deformed/sec (%d vertices, all iters)" % v,
+            "value": n_total * args.steps / elapsed,
             "unit": "contours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: DANCE R50 snake head, %d images x %d "
-                                   "instances x %d vertices per GPU, %d iterations, features "
-                                   "(%d,%d,%d,%d) %s fp32 in HBM" % (b, per, v, ITERS, b, CH + 1, HF, WF,
-                                                                     args.layout.upper()),
-                       "contours_per_gpu": n, "vertices": v, "iterations": ITERS,
+            "config": {"workload": WORKLOAD_NAMES[args.workload] + (
+                           ": ONE sweep of %d images x %d instances x %d vertices split by image over the ranks "
+                           "(this rank: images [%d, %d)), %d iterations, counts + padded RCCL all-gather of the "
+                           "deformed contours; features (%d,%d,%d,%d) %s fp32 in HBM per rank" % (
+                               args.images, per, v, img_lo, img_hi, ITERS, b, CH + 1, HF, WF, args.layout.upper())
+                           if strong else
+                           ": DANCE R50 snake head, %d images x %d instances x %d vertices per GPU, %d iterations, "
+                           "features (%d,%d,%d,%d) %s fp32 in HBM" % (b, per, v, ITERS, b, CH + 1, HF, WF,
+                                                                     args.layout.upper())),
+                       "contours_total": n_total, "contours_per_gpu": n, "vertices": v, "iterations": ITERS,
+                       "chunks_per_iteration": -(-n // deformer.MAX_CHUNK),
                        "precision": args.precision + {
                            "fp16x3": " (fp32-level accuracy: parity 1e-4 norm-wise per iteration vs the fp32 reference)",
                            "fp32": " (exact f32 MFMA)",
@@ -533,15 +685,15 @@ def main():
                                "contour-iteration), not HBM-bound" % (
                                    2.0 * ((CH + 2) * 128 * 9 + (7 * MACS_RES_BLOCK if head_stack else 0)) * v / 1e6),
                        "traffic": measured_traffic("k_head_stack16s" if head_stack else
-                                                   "k_gather_head16" if args.precision != "fp32" else "k_gather_head<", n)[0],
-                       "standalone_traffic": measured_traffic("k_gather|", 4 * n)[0] if v == 128 else None,
+                                                   "k_gather_head16" if args.precision != "fp32" else "k_gather_head<", n_ev)[0],
+                       "standalone_traffic": measured_traffic("k_gather|", 4 * n_ev)[0] if v == 128 else None,
                        "traffic_note": "HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json; "
                                        "neighbouring vertices share taps in L2, so fewer bytes are fetched than the "
                                        "no-reuse algorithmic figure)",
                        "standalone_kernel": "k_gather (gather + de_location + concat only, untimed extra)",
                        "standalone_ms": gather_alone_ms,
-                       "standalone_algorithmic_GBps": GATHER_BYTES_PER_VERTEX * v * n / (gather_alone_ms * 1e-3) / 1e9,
-                       "standalone_frac_of_hbm_peak": GATHER_BYTES_PER_VERTEX * v * n / (gather_alone_ms * 1e-3) / 1e9
+                       "standalone_algorithmic_GBps": GATHER_BYTES_PER_VERTEX * v * n_ev / (gather_alone_ms * 1e-3) / 1e9,
+                       "standalone_frac_of_hbm_peak": GATHER_BYTES_PER_VERTEX * v * n_ev / (gather_alone_ms * 1e-3) / 1e9
                                                       / PEAK_HBM_GBPS},
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms,

@@ -26,6 +26,46 @@ def shard_by_image(image_idx, num_images, rank, world):
     return (idx >= lo) & (idx < hi), lo
 
 
+class ImageShard:
+    """The share of one fixed sweep that rank `rank` of `world` deforms (strong scaling, BASELINE
+    config 5): the contours of the contiguous image block `image_range(num_images, rank, world)`.
+
+    image_idx (N,) must be non-decreasing -- contours grouped by image, as the reference's
+    `sample_bboxes_fast` emits them (snake_head.py:865-886) -- so that the concatenation of the
+    ranks' shards in rank order IS the original contour order and the all-gather needs no permutation.
+      index            positions of the owned contours in the full set (int64)
+      local_image_idx  their image index relative to the first owned image (only the owned images'
+                       feature maps are resident on the rank)
+      images           (lo, hi) block of owned images
+    """
+
+    def __init__(self, image_idx, num_images, rank, world):
+        idx = image_idx.to(torch.int64)
+        if idx.numel() > 1 and bool((idx[1:] < idx[:-1]).any()):
+            raise ValueError("ImageShard: image_idx must be non-decreasing (contours grouped by image)")
+        mask, lo = shard_by_image(idx, num_images, rank, world)
+        self.images = image_range(num_images, rank, world)
+        self.index = mask.nonzero().flatten()
+        self.local_image_idx = (idx[self.index] - lo).to(image_idx.dtype)
+
+    def take(self, t):
+        """Rows of a per-contour tensor that belong to this rank."""
+        return t.index_select(0, self.index.to(t.device))
+
+    def __len__(self):
+        return int(self.index.numel())
+
+
+def gather_shards(local, group=None):
+    """The exchange step of a sharded sweep: every rank's deformed contours (n_r, V, 2), n_r
+    differing with the instances per image, into the full (N, V, 2) set on every rank in the
+    original order: one tiny all-gather of the counts, then one padded all_gather_into_tensor."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    counts = gather_counts(local.size(0), local.device, group)
+    return all_gather_contours(local, counts, group)
+
+
 def all_gather_contours(local, counts=None, group=None):
     """All-gather per-rank contour tensors (n_r, V, 2) into (sum n_r, V, 2) on every rank,
     rank order preserved.

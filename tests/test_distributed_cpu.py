@@ -1,6 +1,9 @@
-"""CPU, world_size 2, gloo: image sharding and the contour all-gather."""
+"""CPU, world_size 2, gloo: image sharding, the contour all-gather and bench.py's own launcher."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
@@ -37,7 +40,19 @@ def _worker(rank, world, port, ret):
         counts = dd.gather_counts(hi - lo, torch.device("cpu"))
         out2 = dd.all_gather_contours(full[lo:hi].clone(), counts)
         ok2 = counts == [7, 3] and torch.equal(out2, full)
-        ret[rank] = bool(ok1 and ok2)
+        # the strong-scaling split of one sweep (bench.py --workload cfg5): ragged instances per
+        # image, a stub "deformer" that depends on the GLOBAL image number; the union of the ranks'
+        # shards must be the full set in the original order
+        per = torch.tensor([3, 1, 4, 1, 5])
+        idx = torch.repeat_interleave(torch.arange(5), per).float()
+        contours = torch.rand((int(per.sum()), v, 2), generator=torch.Generator().manual_seed(3))
+        stub = lambda c, i: c * 2 + i[:, None, None]          # noqa: E731
+        shard = dd.ImageShard(idx, 5, rank, world)
+        assert shard.images == ((0, 3) if rank == 0 else (3, 5)) and len(shard) == (8 if rank == 0 else 6)
+        assert float(shard.local_image_idx.min()) == 0.0
+        local = stub(shard.take(contours), shard.local_image_idx + shard.images[0])
+        ok3 = torch.equal(dd.gather_shards(local), stub(contours, idx))
+        ret[rank] = bool(ok1 and ok2 and ok3)
     finally:
         dist.destroy_process_group()
 
@@ -50,3 +65,42 @@ def test_all_gather_contours_gloo():
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_image_shard_needs_grouped_contours():
+    import pytest
+    with pytest.raises(ValueError):
+        dd.ImageShard(torch.tensor([0., 1., 0.]), 2, 0, 2)
+    one = dd.ImageShard(torch.tensor([0., 0., 1.]), 2, 0, 1)      # world 1: everything
+    assert len(one) == 3 and one.images == (0, 2)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e,
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher around it, as the driver calls it) must run TWO
+    ranks: launcher -> by-image shard -> counts + contour all-gather -> one JSON line from rank 0.
+    --dry-run-cpu swaps RCCL for gloo and the HIP deformer for a stub; everything else is the
+    code path of the real run."""
+    for workload, scaling in (("cfg5", "strong"), ("cfg2", "weak")):
+        r = _bench("--gpus", "2", "--workload", workload, "--dry-run-cpu")
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["ok"] is True and line["scaling"] == scaling and line["dry_run"] is True
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    r = _bench("--gpus", "4", "--dry-run-cpu", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4" in r.stderr
