@@ -116,6 +116,8 @@ def nms(dets, scores, threshold):
     _assert(dets.dim() == 2 and dets.size(1) == 4 and scores.dim() == 1 and scores.size(0) == dets.size(0),
             "dets must be (n, 4) and scores (n,)")
     n = dets.size(0)
+    from .ml_nms import _check_size
+    _check_size(n, "nms")
     order = torch.sort(scores.float(), descending=True, stable=True)[1]
     boxes = torch.cat([dets.float(), scores.float()[:, None]], 1)[order].contiguous()
     cb = (n + 63) // 64

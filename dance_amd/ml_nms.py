@@ -13,6 +13,19 @@ import torch
 
 from ._lib import check, current_stream, lib, ptr
 
+# Largest list one NMS call takes.  The bit mask is (n + 1) * ceil(n / 64) words -- 537 MB at this
+# bound, 137 GB at the 2^20 the C side would accept -- and the greedy sweep is one wavefront
+# walking all column blocks serially.  The detector hands over at most PRE_NMS_TOPK (1000) x 5
+# levels per image (fcose_outputs.py:492-499).
+MAX_BOXES = 65536
+
+
+def _check_size(n, what):
+    if n > MAX_BOXES:
+        raise RuntimeError("%s: %d boxes in one list, at most %d are supported (the IoU bit mask grows with "
+                           "n^2 / 8 bytes and the sweep is serial); cut the list with a score top-k first"
+                           % (what, n, MAX_BOXES))
+
 
 def batched_nms(boxes, scores, idxs, iou_threshold):
     """detectron2.layers.batched_nms / torchvision.ops.batched_nms: (n,4) xyxy, (n,), (n,) ->
@@ -24,6 +37,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
     if boxes.dim() != 2 or boxes.size(1) != 4 or scores.shape != (boxes.size(0),) or idxs.shape != scores.shape:
         raise RuntimeError("batched_nms: boxes (n,4), scores (n,), idxs (n,)")
     n = boxes.size(0)
+    _check_size(n, "batched_nms")
     offsets = idxs.to(boxes) * (boxes.max() + 1)
     order = torch.sort(scores.float(), descending=True, stable=True)[1]
     b = torch.cat([boxes.float() + offsets[:, None].float(), scores.float()[:, None]], 1)[order].contiguous()
@@ -56,6 +70,7 @@ def batched_nms_many(boxes, scores, idxs, iou_threshold):
     lists (`dance_nms_segments_plain`), one host sync for the kept counts."""
     sizes = [int(b.size(0)) for b in boxes]
     total, n_seg = sum(sizes), len(sizes)
+    _check_size(max(sizes, default=0), "batched_nms_many")
     if n_seg == 0:
         return []
     dev = boxes[0].device
