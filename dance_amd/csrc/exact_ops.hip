@@ -6,6 +6,7 @@
 // coordinates are bit-identical to the reference's torch/CUDA op sequence
 // (oracle: oracle/extreme_utils_ref.c).
 #include <math.h>
+#include <mutex>
 
 #include "common.h"
 
@@ -17,7 +18,7 @@ char *error_buffer() { return g_error; }
 using dance::ceil_div;
 using dance::launch_check;
 
-extern "C" int dance_abi_version(void) { return 7; }
+extern "C" int dance_abi_version(void) { return 8; }
 extern "C" const char *dance_last_error(void) { return dance::error_buffer(); }
 
 extern "C" int dance_device_info(int *cu_count_host, int *lds_bytes_host)
@@ -465,8 +466,8 @@ extern "C" int dance_nms_sorted_plain(const float *boxes_sorted, int n, float th
 static int nms_sorted_impl(const float *boxes_sorted, int n, float thresh, int plus_one, uint64_t *mask_ws,
                            int64_t *keep, int32_t *count, void *stream)
 {
-    DANCE_REQUIRE(n >= 0 && n <= (1 << 20));
-    DANCE_REQUIRE(count != nullptr);
+    DANCE_REQUIRE(n >= 0 && n <= (1 << 20));      // 2^20 boxes would need a 137 GB mask: the Python
+    DANCE_REQUIRE(count != nullptr);              // wrappers stop at 65,536 (dance_amd/ml_nms.py)
     if (n == 0)
         return hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess
                    ? 0 : dance::fail((int)hipErrorUnknown, __func__, "memset failed");
@@ -480,6 +481,57 @@ static int nms_sorted_impl(const float *boxes_sorted, int n, float thresh, int p
     hipLaunchKernelGGL(k_nms_sweep, dim3(1), dim3(64), 0, (hipStream_t)stream, n, cb, mask,
                        mask + (long long)n * cb, (long long *)keep, count);
     return launch_check(__func__);
+}
+
+// ------------------------------------------------------------------------------------
+// dance_nms_sorted_plain for callers that cannot allocate (HIP graph capture, tight serving
+// loops): the IoU bit mask and the removal words live in a file-scope device array instead of
+// a caller workspace.  No counterpart in the reference.  Every GPU holds its own copy of the
+// array at its own address; the address is looked up once per device and that pointer -- never
+// the array's name, which on the host is only a stand-in -- is what the kernels receive.
+// ------------------------------------------------------------------------------------
+// DANCE_NMS_STATIC_MAX (include/dance_hip.h) = 4096 boxes: (4096 + 1) * 64 words = 2.0 MiB per GPU
+#define DANCE_MAX_DEVICES 64
+static __device__ __align__(256) unsigned long long scratch[(DANCE_NMS_STATIC_MAX + 1) * (DANCE_NMS_STATIC_MAX / 64)];
+static unsigned long long *g_scratch_ptr[DANCE_MAX_DEVICES];     // per device, set once
+static std::mutex g_scratch_mutex;
+
+static int nms_static_scratch(unsigned long long **out, const char *fn)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return dance::fail((int)e, fn, hipGetErrorString(e));
+    if (dev < 0 || dev >= DANCE_MAX_DEVICES)
+        return dance::fail((int)hipErrorInvalidDevice, fn, "device ordinal beyond DANCE_MAX_DEVICES");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        unsigned long long *p = nullptr;
+        e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));     // the current device's copy
+        if (e != hipSuccess || !p)
+            return dance::fail((int)(e != hipSuccess ? e : hipErrorInvalidSymbol), fn,
+                               "hipGetSymbolAddress(scratch) failed");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int dance_nms_sorted_plain_static(const float *boxes_sorted, int n, float thresh, int64_t *keep,
+                                             int32_t *count, void *stream)
+{
+    if (n > DANCE_NMS_STATIC_MAX)
+        return dance::fail((int)hipErrorInvalidValue, __func__,
+                           "n exceeds the static scratch (at most 4096 boxes; larger lists: "
+                           "dance_nms_sorted_plain with a caller workspace)");
+    DANCE_REQUIRE(n >= 0 && count != nullptr);
+    DANCE_REQUIRE(n == 0 || (boxes_sorted && keep));
+    unsigned long long *ws = nullptr;
+    if (int rc = nms_static_scratch(&ws, __func__))
+        return rc;
+    // nothing in the scratch has to start at zero: k_nms_mask writes every word the sweep reads
+    // (diagonal and right of it) and the sweep clears its removal words itself
+    return nms_sorted_impl(boxes_sorted, n, thresh, 0, (uint64_t *)ws, keep, count, stream);
 }
 
 extern "C" int dance_nms_segments_plain(const float *boxes_sorted, const int64_t *seg, int n_seg, int n_max,

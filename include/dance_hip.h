@@ -73,6 +73,20 @@ int dance_nms_sorted(const float *boxes_sorted, int n, float thresh, uint64_t *m
 int dance_nms_sorted_plain(const float *boxes_sorted, int n, float thresh, uint64_t *mask_ws,
                            int64_t *keep, int32_t *count, void *stream);
 
+/* dance_nms_sorted_plain that allocates nothing and takes no workspace.  NO counterpart in the
+ * reference: it exists for callers that cannot call hipMalloc -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid allocation.  The scratch (IoU bit mask + removal
+ * words) is a file-scope device array of (4096 + 1) * 64 uint64 = 2.0 MiB that every GPU the
+ * library runs on holds until the process ends; its per-device address is looked up at the first
+ * call on that device (hipGetSymbolAddress; no allocation then either).  n <= 4096
+ * (DANCE_NMS_STATIC_MAX), larger lists return hipErrorInvalidValue with a text naming
+ * dance_nms_sorted_plain.  Same results as dance_nms_sorted_plain, bit for bit.  All calls on
+ * one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
+ * serialise them or use the workspace form.  Nothing has to be cleared between calls. */
+#define DANCE_NMS_STATIC_MAX 4096
+int dance_nms_sorted_plain_static(const float *boxes_sorted, int n, float thresh, int64_t *keep,
+                                  int32_t *count, void *stream);
+
 /* dance_nms_sorted_plain for many independent lists in two launches -- the per-image loop of
  * select_over_all_levels (fcose_outputs.py:523-529) without a launch pair and a host sync per
  * image.  boxes_sorted: the segments' (n_i,5) rows back to back, each sorted by descending score;
