@@ -4,7 +4,10 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "../../include/dance_hip.h"
 
@@ -29,6 +32,31 @@ inline int launch_check(const char *fn)
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// A launch with more than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize
+// raised on the kernel -- per DEVICE (the attribute lives with the device's copy of the code
+// object).  Issued once per (kernel, device), again only when a larger size is asked for;
+// thread-safe; no allocation (safe under graph capture).  The one helper every file uses.
+inline int allow_lds(const void *kernel, size_t bytes, const char *fn)
+{
+    if (bytes <= 64 * 1024)
+        return 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return fail((int)e, fn, hipGetErrorString(e));
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = granted[std::make_pair(kernel, dev)];
+    if (have >= bytes)
+        return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return fail((int)e, fn, hipGetErrorString(e));
+    have = bytes;
+    return 0;
+}
 
 // compile-time loop: f(std::integral_constant<int, B>{}), ..., f(<E - 1>)
 template <int B, int E, typename F>

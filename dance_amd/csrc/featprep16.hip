@@ -435,9 +435,8 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
     if (e != hipSuccess)
         return dance::fail((int)e, __func__, hipGetErrorString(e));
     const size_t lds = 2 * C2_BYTES;
-    e = hipFuncSetAttribute((const void *)k_conv3x3_16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess)
-        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    if (int rc = dance::allow_lds((const void *)k_conv3x3_16, lds, __func__))
+        return rc;
     hipLaunchKernelGGL(k_conv3x3_16, dim3((unsigned)(tiles * (cout / 128))), dim3(256), lds, (hipStream_t)stream, a);
     return launch_check(__func__);
 }

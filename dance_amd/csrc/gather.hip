@@ -210,14 +210,8 @@ extern "C" int dance_gather_features(const float *feat, const float *att, const 
     DANCE_REQUIRE(feat && loc && x_out);
     DANCE_REQUIRE(n <= 65535 * 16);
     const size_t lds = ((size_t)c * GV_PAD + GV * 4 + GV * 4 + 16) * sizeof(float);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gather,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess)
-            return dance::fail((int)e, __func__, hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc = dance::allow_lds((const void *)k_gather, lds, __func__))
+        return rc;
     // contours go on grid.y (<= 65535): split very large n over several launches
     for (int n0 = 0; n0 < n; n0 += 65535) {
         const int nb = n - n0 < 65535 ? n - n0 : 65535;

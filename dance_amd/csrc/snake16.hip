@@ -1336,11 +1336,7 @@ int env_int(const char *name, int dflt)
 template <typename K>
 int big_lds(K kernel, size_t bytes, const char *fn)
 {
-    if (bytes <= 64 * 1024)
-        return 0;
-    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)bytes);
-    return e == hipSuccess ? 0 : dance::fail((int)e, fn, hipGetErrorString(e));
+    return dance::allow_lds((const void *)kernel, bytes, fn);      // once per kernel and device
 }
 
 #define LAUNCH_ONE(KERNEL, RTV, terms, grid, block, lds, s, fn, ...)                          \

@@ -386,13 +386,8 @@ int pick_ck(int v, int cin_pad)
 template <int RT>
 int launch_head(dim3 grid, size_t lds, hipStream_t s, const ConvArgs &a, const GatherArgs &g)
 {
-    if (lds > 64 * 1024) {
-        // per device and instantiation; cheap enough to repeat, and safe under capture
-        hipError_t e = hipFuncSetAttribute((const void *)k_gather_head<RT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess)
-            return dance::fail((int)e, "dance_gather_circconv_head", hipGetErrorString(e));
-    }
+    if (int rc = dance::allow_lds((const void *)k_gather_head<RT>, lds, "dance_gather_circconv_head"))
+        return rc;
     hipLaunchKernelGGL(k_gather_head<RT>, grid, dim3(256), lds, s, a, g);
     return launch_check("dance_gather_circconv_head");
 }

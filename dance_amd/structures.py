@@ -46,6 +46,10 @@ class PolygonPoints(_PointSet):
     """(N, V, 2) contour vertices (pointset.py:221-234)."""
 
     def clip(self, box_size):
+        """pointset.py:247-251, the finite check included: a collapsed contour (`derange` divides by
+        max - min with no epsilon, snake_head.py:1588-1593) is NaN there and here, and the reference
+        raises at this point instead of rasterising garbage (one host sync, as in the reference)."""
+        assert torch.isfinite(self.tensor).all(), "Polygon tensor contains infinite or NaN!"
         h, w = box_size
         self.tensor[:, :, 0].clamp_(min=0, max=w)
         self.tensor[:, :, 1].clamp_(min=0, max=h)

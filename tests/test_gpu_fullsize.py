@@ -8,7 +8,8 @@ features where the chain is well conditioned)."""
 import pytest
 import torch
 
-from _util import REL_TOL, FakeBoxes, FakeInstances, coord_rel_err, dance_state_dict, dsnake_state_dict
+from _util import (REL_TOL, FakeBoxes, FakeInstances, assert_coords_close, coord_rel_err, dance_state_dict,
+                   dsnake_state_dict)
 from dance_amd import modules, ops, snake, synthetic
 from oracle import snake_ref
 
@@ -36,15 +37,23 @@ def _dance_inputs(b, per, v, seed, device):
     return boxes, whs, init, idx
 
 
-def _check_sample(preds, sd, feats, init, idx, whs, sample):
-    """oracle on the sampled contours, each with its own image only"""
+def _check_sample(d, preds, sd, feats, init, idx, whs, sample):
+    """oracle on the sampled contours, each with its own image only: the free-running chain
+    (1e-4 norm-wise; band-limited features) and every iteration on identical inputs -- the
+    oracle's previous contours fed to the HIP iteration -- to 1e-4 norm-wise and 0.02 px"""
     for j in sample:
         img = int(idx[j])
         f1 = feats[img:img + 1].cpu()
         want = snake_ref.dance_deform(sd, f1, init[j:j + 1].cpu(), torch.zeros(1), [(HF * 4, WF * 4)],
                                       whs[j:j + 1].cpu())
+        f = d.prepare_features(feats[img:img + 1])
+        prev = init[j:j + 1]
         for it in range(3):
             assert coord_rel_err(preds[it][j:j + 1], want[it]) < REL_TOL, (j, it)
+            one = d.evolve(it, *f, prev.to(feats.device), torch.zeros(1, dtype=torch.int32, device=feats.device),
+                           whs[j:j + 1].to(feats.device), use_att=it > 0, clip_first=False, clip_max=(0, 0))
+            assert_coords_close(one, want[it], "contour %d iteration %d" % (j, it))
+            prev = want[it]
 
 
 def test_config3_dance_32x100_attention(device):
@@ -66,7 +75,7 @@ def test_config3_dance_32x100_attention(device):
     for it in range(3):
         assert torch.equal(preds[it], again[it])
         assert torch.equal(preds[it][perm], shuffled[it])
-    _check_sample(preds, sd, feats, init, idx, whs, [0, 1234, 3199])
+    _check_sample(d, preds, sd, feats, init, idx, whs, [0, 1234, 3199])
 
 
 def test_config4_dsnake_32x100(device):
@@ -115,4 +124,4 @@ def test_config5_large_sweep_256v(device):
                          whs[sl].to(device))
         for it in range(3):
             assert torch.equal(alone[it], preds[it][sl]), (img, it)
-    _check_sample(preds, sd, feats, init, idx, whs, [7, 40000, 76799])
+    _check_sample(d, preds, sd, feats, init, idx, whs, [7, 40000, 76799])

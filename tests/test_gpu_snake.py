@@ -4,7 +4,7 @@ relative per iteration (north_star), intermediate activations within 1e-4 of the
 import pytest
 import torch
 
-from _util import (CHAIN_TOL_SMOOTH, CHAIN_TOL_WHITE, REL_TOL, coord_rel_err, dance_state_dict,
+from _util import (CHAIN_TOL_SMOOTH, CHAIN_TOL_WHITE, REL_TOL, assert_coords_close, coord_rel_err, dance_state_dict,
                    dsnake_state_dict, golden, rel_err)
 from dance_amd import modules, ops, snake, synthetic
 from oracle import snake_ref
@@ -144,16 +144,20 @@ def test_dance_chain_golden(device, tag, mode):
                               fused_head=mode != "fp32-unfused", precision=mode.split("-")[0])
     idx = None if image_idx is None else image_idx.to(device)
     preds = d.deform(feats.to(device), g["init"].to(device), idx, sizes, g["whs"].to(device))
-    tol = CHAIN_TOL_SMOOTH if int(g["smooth"]) else CHAIN_TOL_WHITE
-    for i in range(3):
-        # (a) the chain as the reference ran it
-        assert coord_rel_err(preds[i], g["pred%d" % i]) < tol[i], (tag, i)
-    # (b) per iteration on identical inputs: feed the reference's iteration input
+    # (a) THE GATE -- every iteration on identical inputs (iteration 0 from the initial contours,
+    # iterations 1, 2 fed the reference's own previous contours): 1e-4 norm-wise and 0.02 px
+    assert_coords_close(preds[0], g["pred0"], "%s iteration 0" % tag)
     for i in range(1, 3):
         one = d.evolve(i, *d.prepare_features(feats.to(device)), g["pred%d" % (i - 1)].to(device), idx,
                        g["whs"].to(device), use_att=cfg.attention, clip_first=image_idx is None,
                        clip_max=(sizes[1] - 1, sizes[0] - 1) if image_idx is None else (0, 0))
-        assert coord_rel_err(one, g["pred%d" % i]) < REL_TOL, (tag, i)
+        assert_coords_close(one, g["pred%d" % i], "%s iteration %d" % (tag, i))
+    # (b) the free-running chain as the reference ran it: held to 1e-4 on the band-limited
+    # fixtures; on white-noise features the chain is chaotic (DESIGN.md "Parity") and only a
+    # sanity bound is checked after iteration 0 -- not a parity gate, (a) is
+    tol = CHAIN_TOL_SMOOTH if int(g["smooth"]) else CHAIN_TOL_WHITE
+    for i in range(3):
+        assert coord_rel_err(preds[i], g["pred%d" % i]) < tol[i], (tag, i)
 
 
 @pytest.mark.parametrize("tag", ["smooth_single_box_v128", "smooth_batched_box_v196"])
