@@ -30,7 +30,7 @@ SOURCES = [
     ("attender.hip", []),
     ("fcose.hip", ["-ffp-contract=off"]),
 ]
-HEADERS = ["common.h", "sampling.h", "p16.h", os.path.join("..", "..", "include", "dance_hip.h")]
+HEADERS = ["common.h", "sampling.h", "p16.h", "mfma16.h", os.path.join("..", "..", "include", "dance_hip.h")]
 
 
 def _newer(target, deps):

@@ -22,14 +22,13 @@
 // + row constant + prediction[0], the 1024-channel state read once), k_gather_head16 (gather
 // + de_location + head block).
 #include "common.h"
+#include "mfma16.h"
 #include "p16.h"
 #include "sampling.h"
 
 using dance::launch_check;
 
 namespace {
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct Conv16Args {
     const _Float16 *x;          // P16 input
@@ -46,116 +45,6 @@ struct Conv16Args {
     const float *rowinit;       // per-contour accumulator start (n, cout), unscaled, or null
     int v, cin, cout, taps, dilation, relu, residual, maxv;
 };
-
-__device__ __forceinline__ int ring16(int vv, int off, int v)
-{
-    int t = vv + off;
-    t = t < 0 ? t + v : t;
-    t = t >= v ? t - v : t;
-    t = t >= v ? t - v : t;
-    return t;
-}
-
-// Geometry of one LDS chunk image: [plane 2][CBC channel blocks][VP words of 16 B].
-template <int RT, int CBC>
-struct Geo {
-    static constexpr int VP = RT * 32 + 1;          // odd row stride: conflict-free b128 reads
-    static constexpr int CPR = (RT + 1) / 2;        // 64-lane passes along a row
-    static constexpr int PLANE = CBC * VP * 16;     // bytes
-    static constexpr int BYTES = 2 * PLANE;
-};
-
-// acc[ot][rt] += W[o-tiles, chunk] * X[chunk, :] for one LDS-resident chunk of 2 * NST channel
-// blocks.
-//   xs + lds0   : the chunk image (Geo<RT, 2 * NST>)
-//   wchunk      : uniform byte pointer to W[plane 0][tap 0][chunk's first block][wave's o-tile 0]
-//   wlane       : this lane's constant byte offset ((h * cout + r) * 16)
-//   wps_b / wts_b / wstep_b : byte strides of a plane / a tap / two channel blocks (one step)
-//   hook(s)     : called once per step of tap 0, after the step's weight prefetch was issued
-//                 (the place for staged activation loads)
-// AD weight buffers rotate (prefetch distance AD - 1 steps); NB vertex-tile (B) buffers rotate
-// over the flat tile sequence q = s * RT + rt (prefetch distance NB - 1 tiles).
-template <int RT, int OTW, int NST, int AD, int NB, int TERMS, typename Hook>
-__device__ __forceinline__ void mfma16_core(f32x16 (&acc)[OTW][RT], const char *xs, unsigned lds0, int v,
-                                            const char *wchunk, unsigned wlane, long long wps_b,
-                                            long long wts_b, long long wstep_b, int taps, int dilation,
-                                            int r, int h, Hook hook)
-{
-    constexpr int NT = NST * RT, DB = NB - 1, D = AD - 1;
-    static_assert(NST % AD == 0 && D <= NST, "weight buffer rotation must close over a tap");
-    static_assert(NT % NB == 0 && DB <= NT - RT && DB >= 1, "tile buffer rotation must close over a tap");
-    using G = Geo<RT, 2 * NST>;
-    constexpr int SSTEP = 2 * G::VP * 16;
-    const unsigned rowb = lds0 + h * G::VP * 16;
-    const unsigned lim = rowb + v * 16, d16 = dilation * 16, v16 = v * 16;
-    unsigned p[RT];                             // LDS byte address of this lane's word, per vertex tile
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-        p[rt] = rowb + ring16(rt * 32 + r, -(taps >> 1) * dilation, v) * 16;
-
-    h8 ah[AD][OTW], al[AD][OTW];
-#define DANCE_LOAD_A(SLOT, PTR)                                                                   \
-    do {                                                                                          \
-        const char *pa_ = (PTR);                                                                  \
-        _Pragma("unroll") for (int ot_ = 0; ot_ < OTW; ++ot_) {                                   \
-            ah[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wlane + ot_ * 512);               \
-            if constexpr (TERMS == 3)                                                             \
-                al[SLOT][ot_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + ot_ * 512);   \
-        }                                                                                         \
-    } while (0)
-    // tile Q of the current tap (Q < NT) or of the next one (p[] of its vertex tile already
-    // advanced); p[rt] advances right after its last use in a tap (the fetch of step NST - 1)
-#define DANCE_LOAD_B(Q)                                                                           \
-    do {                                                                                          \
-        constexpr int q_ = (Q) % NT, s_ = q_ / RT, rt_ = q_ % RT;                                 \
-        bh[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[rt_] + s_ * SSTEP);                   \
-        if constexpr (TERMS == 3)                                                                 \
-            bl[(Q) % NB] = *reinterpret_cast<const h8 *>(xs + p[rt_] + s_ * SSTEP + G::PLANE);    \
-        if (s_ == NST - 1) {                                                                      \
-            const unsigned tpos_ = p[rt_] + d16;                                                  \
-            p[rt_] = tpos_ >= lim ? tpos_ - v16 : tpos_;                                          \
-        }                                                                                         \
-    } while (0)
-#pragma unroll
-    for (int q = 0; q < D; ++q)
-        DANCE_LOAD_A(q, wchunk + q * wstep_b);
-    h8 bh[NB], bl[NB];
-    dance::static_for<0, DB>([&](auto q) __attribute__((always_inline)) { DANCE_LOAD_B(decltype(q)::value); });
-
-    const char *wtap = wchunk;
-    for (int tap = 0; tap < taps; ++tap) {
-        const bool more = tap + 1 < taps;
-        dance::static_for<0, NT>([&](auto qq) __attribute__((always_inline)) {
-            constexpr int q = decltype(qq)::value, s = q / RT, rt = q % RT;
-            if constexpr (rt == 0) {
-                if (s + D < NST)
-                    DANCE_LOAD_A((s + D) % AD, wtap + (s + D) * wstep_b);
-                else if (more)
-                    DANCE_LOAD_A((s + D) % AD, wtap + wts_b + (s + D - NST) * wstep_b);
-                if (tap == 0)
-                    hook(s);
-            }
-            DANCE_LOAD_B(q + DB);
-            // keep the prefetch ahead of this tile's MFMAs (the scheduler otherwise sinks it
-            // below them and the rotation collapses into load -> wait -> use)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (TERMS == 3) {
-#pragma unroll
-                for (int ot = 0; ot < OTW; ++ot)
-                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s % AD][ot], bh[q % NB], acc[ot][rt], 0, 0, 0);
-#pragma unroll
-                for (int ot = 0; ot < OTW; ++ot)
-                    acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bl[q % NB], acc[ot][rt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int ot = 0; ot < OTW; ++ot)
-                acc[ot][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % AD][ot], bh[q % NB], acc[ot][rt], 0, 0, 0);
-        });
-        wtap += wts_b;
-    }
-#undef DANCE_LOAD_A
-#undef DANCE_LOAD_B
-}
 
 // The same contraction on v_mfma_f32_16x16x32_f16 (K = 32 channels = 4 channel blocks per
 // MFMA, 16 x 16 output tiles): the chip holds a higher clock on this shape under load
@@ -359,26 +248,6 @@ __device__ __forceinline__ void stage_commit(const u32x4 (&reg)[(StageGeo<RT, CB
     }
 }
 
-template <int RT, int OTW>
-__device__ __forceinline__ void init_acc16(f32x16 (&acc)[OTW][RT], const float *bias_s, int o0, int h, float mul)
-{
-#pragma unroll
-    for (int ot = 0; ot < OTW; ++ot)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 b = {0.f, 0.f, 0.f, 0.f};
-            if (bias_s)
-                b = *reinterpret_cast<const float4 *>(bias_s + o0 + ot * 32 + 8 * g + 4 * h);
-            const float bb[4] = {b.x * mul, b.y * mul, b.z * mul, b.w * mul};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[ot][rt][4 * g + i] = bb[i];
-        }
-}
-
-__device__ __forceinline__ float relu_nan(float x) { return x > 0.0f ? x : (x != x ? x : 0.0f); }
 
 // Residual SnakeBlock / k=1 Conv1d.  4 waves, one 32-channel tile each (128 outputs per
 // workgroup, grid.y tiles of 128); chunks of 64 (V <= 128) or 32 channels double-buffered in
