@@ -25,6 +25,7 @@ SOURCES = [
     ("gather.hip", []),
     ("snake_mfma.hip", []),
     ("snake16.hip", []),
+    ("tail16.hip", []),
     ("featprep16.hip", []),
     ("raster.hip", ["-ffp-contract=off"]),
     ("attender.hip", []),

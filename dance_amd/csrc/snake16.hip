@@ -220,9 +220,11 @@ struct StageGeo {
 };
 
 // src: uniform byte pointer to (plane 0, chunk's first block) of the P16 slot
+// vs: vertices per row of the P16 slot in memory (the ring length); v: vertices staged (a part
+// of the ring when the caller splits it, src then points at the part's first vertex)
 template <int RT, int CBC, int NW>
 __device__ __forceinline__ void stage_load(u32x4 (&reg)[(StageGeo<RT, CBC, NW>::N)], int jlo, int jhi,
-                                           const char *src, int v, int wave, int lane)
+                                           const char *src, int v, int wave, int lane, int vs)
 {
     using S = StageGeo<RT, CBC, NW>;
 #pragma unroll
@@ -231,8 +233,15 @@ __device__ __forceinline__ void stage_load(u32x4 (&reg)[(StageGeo<RT, CBC, NW>::
             const int row = wave + NW * (j / S::G::CPR);
             const int plane = row >= CBC ? 1 : 0, cbl = row - plane * CBC;
             const unsigned col = min((j % S::G::CPR) * 64 + lane, v - 1);
-            reg[j] = *reinterpret_cast<const u32x4 *>(src + (plane * 256ll + cbl * 16ll) * v + col * 16u);
+            reg[j] = *reinterpret_cast<const u32x4 *>(src + (plane * 256ll + cbl * 16ll) * vs + col * 16u);
         }
+}
+
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_load(u32x4 (&reg)[(StageGeo<RT, CBC, NW>::N)], int jlo, int jhi,
+                                           const char *src, int v, int wave, int lane)
+{
+    stage_load<RT, CBC, NW>(reg, jlo, jhi, src, v, wave, lane, v);
 }
 
 template <int RT, int CBC, int NW>
@@ -775,22 +784,36 @@ __global__ __launch_bounds__(512) void k_res_stack16w(Stack16Args a, int n)
 // fusion (1024 -> 256, max over the ring) + row constant + prediction[0] (1280 -> 256, ReLU)
 // in one pass over the 1024-channel state: 8 waves, two 32-channel tiles each; waves 0-3 own
 // the fusion outputs, waves 4-7 the prediction outputs (weights packed as one 512-output GEMM).
-// Chunks of 64 channels, double-buffered like k_conv16 (one staged load per step).
+// Chunks of 128 channels, double-buffered like k_conv16 (one staged load per step).
+//
+// Two forms of the same K loop:
+//   fused (k_fuse16, rings of at most 128 vertices): max -> row constant (a 256 x 256 GEMV per
+//     contour) -> relu(prediction[0]) inside the kernel; the fusion and the prediction waves take
+//     turns waiting for each other at the end.
+//   raw (k_fuse16r, any ring up to 256 vertices): both k = 1 convolutions are pointwise over
+//     the ring, so the ring may be split into PARTS of at most 128 vertices (blockIdx.y), each
+//     a workgroup of its own.  A part writes the max of the fusion output over ITS vertices
+//     (gpart) and prediction[0]'s state part WITHOUT row constant and ReLU; k_tail16 (tail16.hip)
+//     reduces the parts, forms the row constant and goes on with relu -> prediction[2] ->
+//     prediction[4] -> offset update.  No cross-wave hand-over at the end of this kernel.
 struct Fuse16Args {
     const _Float16 *x;
     long long x_stride, x_slot_stride;
     const h8 *w;                  // [plane][1][128][512]
     const float *bias_s;          // (512): fusion bias * 2^s, then zeros
-    const float *wg;              // (256, 256) [g][o] fp32: global-state columns of prediction[0]
-    const float *pb;              // (256) prediction[0] bias
+    const float *wg;              // (256, 256) [g][o] fp32: global-state columns of prediction[0] (fused form)
+    const float *pb;              // (256) prediction[0] bias (fused form)
     float winv;
     _Float16 *y;                  // P16, 2 slots
     long long y_stride, y_slot_stride;
-    int v;
+    int v;                        // ring length = vertices per row of x and y
+    float *gpart;                 // raw form: (n, parts, 256) max of the fusion output over each part
+    int part_v;                   // raw form: vertices of every part but the last
 };
 
-template <int RT, int TERMS>
-__global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
+// v0 / v: first vertex and vertex count of this workgroup's part of the ring (0 / a.v: whole ring)
+template <int RT, int TERMS, bool RAW>
+__device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, int v, int part, int parts)
 {
     // K = 1024 as one flat sequence of 64 steps of 16 channels: weights rotate through two
     // buffers over the whole sequence (no refill bubble at chunk boundaries), activations come
@@ -801,25 +824,23 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
     using S = StageGeo<RT, CBC, NW>;
     constexpr int SSTEP = 2 * G::VP * 16;
     extern __shared__ __attribute__((aligned(16))) char xs[];
-    __shared__ float gs[256];
-    __shared__ float hp[8 * 256];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int o0 = wave * 64;
-    const int v = a.v;
+    const int vs = a.v;
     const long long wbs_b = 512 * 16, wps_b = 128 * wbs_b, wstep_b = 2 * wbs_b;
     const unsigned wlane = (unsigned)(h * 512 + r) * 16u;
     const int ostep = gridDim.x;
     const char *wbase = reinterpret_cast<const char *>(a.w) + (long long)o0 * 16;
 
     auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
-        return reinterpret_cast<const char *>(a.x + m * a.x_stride + c * a.x_slot_stride);
+        return reinterpret_cast<const char *>(a.x + m * a.x_stride + c * a.x_slot_stride) + v0 * 16;
     };
 
     u32x4 sreg[S::N];
     long long nn = blockIdx.x;
-    stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane);
+    stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane, vs);
     stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
     __syncthreads();
 
@@ -864,7 +885,7 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
                     // next step's weights: the sequence runs on linearly into the next chunk
                     if (s + 1 < NST || !last)
                         F_LOAD_A((s + 1) % 2, wchunk + (s + 1) * wstep_b);
-                    stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane);
+                    stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane, vs);
                 }
                 if constexpr (q + 1 < NT)
                     F_LOAD_B(q + 1);
@@ -886,10 +907,10 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
 #undef F_LOAD_A
         int re = r, he = h;
         asm volatile("" : "+v"(re), "+v"(he));
-        if (wave < 4) {
-            // global state = max over the ring of the fusion output (snake_head.py:271-272).
-            // The 32 cross-lane reductions run side by side, one butterfly round at a time
-            // (32 independent shuffles per round instead of 32 serial five-round chains).
+        // max over the (part of the) ring of the fusion output (snake_head.py:271-272).
+        // The 32 cross-lane reductions run side by side, one butterfly round at a time
+        // (32 independent shuffles per round instead of 32 serial five-round chains).
+        auto ring_max = [&](float *dst) __attribute__((always_inline)) {
             float m[2][16];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
@@ -914,67 +935,116 @@ __global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
                 for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        gs[o0 + ot * 32 + (q & 3) + 8 * (q >> 2) + 4 * he] = m[ot][q];
+                        dst[o0 + ot * 32 + (q & 3) + 8 * (q >> 2) + 4 * he] = m[ot][q];
             }
-        }
-        __syncthreads();
-        {   // row constant h[o] = pb[o] + sum_g wg[g][o] * G[g]: 8 partial sums per output, each
-            // thread 4 consecutive outputs x 32 values of g, 8 16-byte loads in flight per round
-            // (a 128-step dependent loop per thread was latency-bound: ~25 us per contour)
-            const int o4 = (t & 63) * 4, part = t >> 6;
-            const float *wgp = a.wg + (long long)part * 32 * 256 + o4;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        };
+        if constexpr (RAW) {
+            if (wave < 4) {
+                ring_max(a.gpart + (nn * parts + part) * 256);
+            } else {
+                const int p0 = o0 - 256;                    // prediction output channel of tile 0
+                _Float16 *yn = a.y + nn * a.y_stride;
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ob = p0 + ot * 32 + 8 * g;
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const int vv = rt * 32 + re;
+                            if (vv >= v)
+                                continue;
+                            float val[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                val[i] = acc[ot][rt][4 * g + i] * a.winv;
+                            dance::store_p16(yn + (ob >> 7) * a.y_slot_stride, vs, (ob & 127) >> 3, v0 + vv, he, val);
+                        }
+                    }
+            }
+        } else {
+            __shared__ float gs[256];
+            __shared__ float hp[8 * 256];
+            if (wave < 4)
+                ring_max(gs);
+            __syncthreads();
+            {   // row constant h[o] = pb[o] + sum_g wg[g][o] * G[g]: 8 partial sums per output, each
+                // thread 4 consecutive outputs x 32 values of g, 8 16-byte loads in flight per round
+                // (a 128-step dependent loop per thread was latency-bound: ~25 us per contour)
+                const int o4 = (t & 63) * 4, prt = t >> 6;
+                const float *wgp = a.wg + (long long)prt * 32 * 256 + o4;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 1
-            for (int k0 = 0; k0 < 32; k0 += 8) {            // 8 loads in flight per round
-                float4 w4[8];
+                for (int k0 = 0; k0 < 32; k0 += 8) {            // 8 loads in flight per round
+                    float4 w4[8];
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk)
-                    w4[kk] = *reinterpret_cast<const float4 *>(wgp + (k0 + kk) * 256);
+                    for (int kk = 0; kk < 8; ++kk)
+                        w4[kk] = *reinterpret_cast<const float4 *>(wgp + (k0 + kk) * 256);
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const float gk = gs[part * 32 + k0 + kk];
-                    s0 = fmaf(w4[kk].x, gk, s0);
-                    s1 = fmaf(w4[kk].y, gk, s1);
-                    s2 = fmaf(w4[kk].z, gk, s2);
-                    s3 = fmaf(w4[kk].w, gk, s3);
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const float gk = gs[prt * 32 + k0 + kk];
+                        s0 = fmaf(w4[kk].x, gk, s0);
+                        s1 = fmaf(w4[kk].y, gk, s1);
+                        s2 = fmaf(w4[kk].z, gk, s2);
+                        s3 = fmaf(w4[kk].w, gk, s3);
+                    }
                 }
+                *reinterpret_cast<float4 *>(hp + prt * 256 + o4) = float4{s0, s1, s2, s3};
             }
-            *reinterpret_cast<float4 *>(hp + part * 256 + o4) = float4{s0, s1, s2, s3};
-        }
-        __syncthreads();
-        if (wave >= 4) {
-            const int p0 = o0 - 256;                        // prediction output channel of tile 0
-            _Float16 *yn = a.y + nn * a.y_stride;
+            __syncthreads();
+            if (wave >= 4) {
+                const int p0 = o0 - 256;                        // prediction output channel of tile 0
+                _Float16 *yn = a.y + nn * a.y_stride;
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot)
+                for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float hc[4];
+                    for (int g = 0; g < 4; ++g) {
+                        float hc[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int o = p0 + ot * 32 + 8 * g + 4 * he + i;
-                        float hs = a.pb[o];
+                        for (int i = 0; i < 4; ++i) {
+                            const int o = p0 + ot * 32 + 8 * g + 4 * he + i;
+                            float hs = a.pb[o];
 #pragma unroll
-                        for (int pp = 0; pp < 8; ++pp)
-                            hs += hp[pp * 256 + o];
-                        hc[i] = hs;
+                            for (int pp = 0; pp < 8; ++pp)
+                                hs += hp[pp * 256 + o];
+                            hc[i] = hs;
+                        }
+                        const int ob = p0 + ot * 32 + 8 * g;
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            const int vv = rt * 32 + re;
+                            if (vv >= v)
+                                continue;
+                            float val[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                val[i] = relu_nan(acc[ot][rt][4 * g + i] * a.winv + hc[i]);
+                            dance::store_p16(yn + (ob >> 7) * a.y_slot_stride, vs, (ob & 127) >> 3, vv, he, val);
+                        }
                     }
-                    const int ob = p0 + ot * 32 + 8 * g;
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const int vv = rt * 32 + re;
-                        if (vv >= v)
-                            continue;
-                        float val[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            val[i] = relu_nan(acc[ot][rt][4 * g + i] * a.winv + hc[i]);
-                        dance::store_p16(yn + (ob >> 7) * a.y_slot_stride, v, (ob & 127) >> 3, vv, he, val);
-                    }
-                }
+            }
+            // gs / hp are rewritten only after the next contour's chunk barriers
         }
-        // gs / hp are rewritten only after the next contour's chunk barriers
     }
+}
+
+template <int RT, int TERMS>
+__global__ __launch_bounds__(512) void k_fuse16(Fuse16Args a, int n)
+{
+    fuse16_body<RT, TERMS, false>(a, n, 0, a.v, 0, 1);
+}
+
+// raw form: grid (contours, parts); every part but the last has RTA * 32 = a.part_v vertices,
+// the last one what remains (at most RTB * 32)
+template <int RTA, int RTB, int TERMS>
+__global__ __launch_bounds__(512) void k_fuse16r(Fuse16Args a, int n)
+{
+    const int part = blockIdx.y, parts = gridDim.y;
+    const int v0 = part * a.part_v, vn = min(a.part_v, a.v - v0);
+    if (RTB != RTA && part + 1 == parts)
+        fuse16_body<RTB, TERMS, true>(a, n, v0, vn, part, parts);
+    else
+        fuse16_body<RTA, TERMS, true>(a, n, v0, vn, part, parts);
 }
 
 // Fused gather + de_location + head SnakeBlock, P16 flavour: chunks of 64 feature channels
@@ -1393,6 +1463,64 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     static const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
     dim3 grid(slots > 0 && slots < n ? slots : n);
     LAUNCH_RT24(k_fuse16, rt, mfma_terms, grid, dim3(512), lds, (hipStream_t)stream, "dance_fuse16", a, n);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_fuse16_parts(int v)
+{
+    return v > 128 ? 2 : 1;
+}
+
+extern "C" int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
+                                const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
+                                int64_t y_slot_stride, float *gpart, int n, int v, int mfma_terms,
+                                void *stream)
+{
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(x && w16 && bias_scaled && y16 && gpart);
+    Fuse16Args a;
+    a.x = (const _Float16 *)x; a.x_stride = x_stride; a.x_slot_stride = x_slot_stride;
+    a.w = (const h8 *)w16; a.bias_s = bias_scaled; a.wg = nullptr; a.pb = nullptr; a.winv = w_inv_scale;
+    a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
+    a.gpart = gpart;
+    // 32-wide vertex tiles; rings above 128 vertices as two parts of rta and rtb tiles
+    const int tiles = dance::ceil_div(v, 32), parts = dance_fuse16_parts(v);
+    const int rta = parts == 1 ? (tiles < 2 ? 2 : tiles) : (tiles + 1) / 2, rtb = parts == 1 ? rta : tiles - rta;
+    a.part_v = parts == 1 ? v : rta * 32;
+    const size_t lds = (size_t)2 * 2 * 16 * (rta * 32 + 1) * 16;   // two 128-channel chunk images
+    static const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
+    dim3 grid(slots > 0 && slots < n ? slots : n, parts);
+    int rc_ = 0;
+#define FUSE_RAW(A, B)                                                                             \
+    do {                                                                                           \
+        if (mfma_terms == 1) {                                                                     \
+            rc_ = dance::allow_lds((const void *)k_fuse16r<A, B, 1>, lds, "dance_fuse16_raw");     \
+            if (!rc_)                                                                              \
+                hipLaunchKernelGGL((k_fuse16r<A, B, 1>), grid, dim3(512), lds, (hipStream_t)stream, a, n); \
+        } else {                                                                                   \
+            rc_ = dance::allow_lds((const void *)k_fuse16r<A, B, 3>, lds, "dance_fuse16_raw");     \
+            if (!rc_)                                                                              \
+                hipLaunchKernelGGL((k_fuse16r<A, B, 3>), grid, dim3(512), lds, (hipStream_t)stream, a, n); \
+        }                                                                                          \
+    } while (0)
+    if (rta == 2 && rtb == 2)
+        FUSE_RAW(2, 2);
+    else if (rta == 3 && rtb == 3)
+        FUSE_RAW(3, 3);
+    else if (rta == 4 && rtb == 4)
+        FUSE_RAW(4, 4);
+    else if (rta == 3 && rtb == 2)
+        FUSE_RAW(3, 2);
+    else if (rta == 4 && rtb == 3)
+        FUSE_RAW(4, 3);
+    else
+        return dance::fail((int)hipErrorInvalidValue, __func__, "unsupported split of the ring");
+#undef FUSE_RAW
+    if (rc_)
+        return rc_;
     return launch_check(__func__);
 }
 

@@ -705,6 +705,27 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
                                net->dilation[i], mfma_terms, stream));
         DANCE_TRY(mark());
     }
+    // default: the raw form of the fusion kernel (any ring length, rings above 128 vertices as
+    // two parts) + k_tail16 (parts' max, row constant, ReLU, prediction[2], prediction[4], offset
+    // update).  DANCE_TAIL16=0 restores the earlier sequence.
+    static const int use_tail = getenv("DANCE_TAIL16") ? atoi(getenv("DANCE_TAIL16")) : 1;
+    if (use_tail) {
+        const int parts = dance_fuse16_parts(v);
+        float *gpart = w.gmax;                  // (n, parts <= 2, 256): gmax and h are adjacent pieces
+        DANCE_REQUIRE(w.h == w.gmax + (long long)n * 256);
+        DANCE_TRY(dance_fuse16_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
+                                   pstride, slot, gpart, n, v, mfma_terms, stream));
+        DANCE_TRY(mark());
+        DANCE_TRY(mark());      // row constant: inside the tail kernel
+        DANCE_TRY(mark());      // prediction[0]'s ReLU: inside the tail kernel
+        DANCE_TRY(mark());      // prediction[2]: the tail kernel, booked on the last stage
+        DANCE_TRY(dance_tail16(p1, pstride, slot, gpart, parts, net->pred0_wg, net->pred0_b, net->pred1_w,
+                               net->pred1_bs, net->pred1_winv, net->pred2_w, net->pred2_b, loc,
+                               individual_scale ? whs : nullptr, use_att ? w.att_s : nullptr, out, n, v,
+                               clip_first, clip_x_max, clip_y_max, mfma_terms, stream));
+        DANCE_TRY(mark());
+        return 0;
+    }
     if (v <= 128) {
         DANCE_TRY(dance_fuse16(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv,
                                net->pred0_wg, net->pred0_b, p1, pstride, slot, n, v, mfma_terms, stream));

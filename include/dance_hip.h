@@ -382,6 +382,28 @@ int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stride, const v
                  const float *pred_bias, void *y16, int64_t y_stride, int64_t y_slot_stride, int n,
                  int v, int mfma_terms, void *stream);
 
+/* The raw form of dance_fuse16 for any ring up to 256 vertices: the same 512-output GEMM, but the
+ * kernel stops before the row constant.  Both convolutions are pointwise over the ring, so rings
+ * above 128 vertices are split into dance_fuse16_parts(v) parts, one workgroup each.  Outputs:
+ * gpart (n, parts, 256) f32 = max of the fusion output over each part's vertices, and y16 (2-slot
+ * P16) = the 1024 state columns of prediction[0] applied to the state, WITHOUT bias / row constant
+ * / ReLU.  dance_tail16 takes both.  reference: _SnakeNet.forward snake_head.py:269-278. */
+int dance_fuse16_parts(int v);
+int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
+                     const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
+                     int64_t y_slot_stride, float *gpart, int n, int v, int mfma_terms, void *stream);
+
+/* The end of a _SnakeNet and of evolve in one launch: global state = max over gpart's parts ->
+ * row constant h = pred0_bias + wg^T g (as dance_row_constant) -> relu(p1 + h) -> prediction[2]
+ * (w1_16: packed (2,1,32,64,8), b1_scaled, w1_inv_scale) + ReLU -> prediction[4] + offset update
+ * exactly as dance_offset_update (same arguments).  The (n,64,v) block between the last two
+ * stays on chip.  reference: snake_head.py:272-282 (row constant, prediction), 1702-1727. */
+int dance_tail16(const void *p1, int64_t p1_stride, int64_t p1_slot_stride, const float *gpart,
+                 int parts, const float *wg, const float *pred0_bias, const void *w1_16,
+                 const float *b1_scaled, float w1_inv_scale, const float *w3, const float *b3,
+                 const float *loc, const float *whs, const float *att, float *out, int n, int v,
+                 int clip_first, float clip_x_max, float clip_y_max, int mfma_terms, void *stream);
+
 /* Fused gather + de_location + head SnakeBlock writing slot 0 of a P16 block
  * (as dance_gather_circconv_head; c % 64 == 0). */
 int dance_gather_head16(const float *feat, const float *att, const float *loc,
