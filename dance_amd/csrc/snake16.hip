@@ -687,22 +687,93 @@ __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
 // The residual stack for rings of 129..256 vertices: 8 waves = 4 output-channel tiles x 2 halves
 // of the ring's 16-wide vertex tiles, the 128-channel image (115 / 132 KB) resident in LDS, one
 // workgroup per CU.  Same arithmetic per output element as k_conv16 / k_conv16s.
-template <int RT, int TERMS>
+// A wave's share of the layers: CTW vertex tiles starting at tile j0 (the image sits in LDS behind
+// a barrier; every wave of the workgroup runs this with the same number of barriers).
+template <int RT, int CTW, int TERMS>
+__device__ __forceinline__ void res_stack16w_layers(const Stack16Args &a, _Float16 *sn, char *xs, int o0, int j0,
+                                                    int c16, int q4)
+{
+    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NB = (NST * CTW) % 4 == 0 ? 4 : 2;
+    using G = Geo<RT, CBC>;
+    const int v = a.v;
+    const long long wbs_b = 128 * 16, wts_b = 16 * wbs_b, wps_b = 9 * wts_b;
+    const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
+    auto nohook = [](int) __attribute__((always_inline)) {};
+    for (int l = 0; l < a.nlayers; ++l) {
+        f32x4 acc[2][CTW];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s[l] + o0 + 16 * i + 4 * q4);
+            const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int j = 0; j < CTW; ++j)
+                acc[i][j] = bv;
+        }
+        const char *wl = reinterpret_cast<const char *>(a.w[l]) + (long long)o0 * 16;
+        const int dil = a.dilation[l];
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c)
+            mfma16_core_sw<RT, CTW, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b,
+                                                        wlane, wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, j0, nohook);
+        __syncthreads();                    // every wave has read the whole image
+        int ce = c16, qe = q4;
+        asm volatile("" : "+v"(ce), "+v"(qe));
+        _Float16 *yslot = sn + (l + 1) * a.slot;
+        const float winv = a.winv[l];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int ob = o0 + 16 * i2 + 4 * qe;
+            const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale[l] + ob);
+            const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift[l] + ob);
+            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
+            const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
+#pragma unroll
+            for (int j = 0; j < CTW; ++j) {
+                const int vv = (j0 + j) * 16 + ce;
+                if (vv >= v)
+                    continue;
+                char *q = xs + xchunk * G::BYTES + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
+                const h4 rh = *reinterpret_cast<const h4 *>(q);
+                const h4 rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
+                h4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
+                    x += (float)rh[i] + (float)rl[i];
+                    _Float16 xh, xl;
+                    dance::split_half(x, xh, xl);
+                    hi[i] = xh;
+                    lo[i] = xl;
+                }
+                *reinterpret_cast<h4 *>(q) = hi;
+                *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
+                _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
+                *reinterpret_cast<h4 *>(d) = hi;
+                *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
+            }
+        }
+        __syncthreads();                    // image = block l + 1's input
+    }
+}
+
+// CTB: vertex tiles of the second group of waves (RT for an even split of 2 * RT tiles; RT - 1
+// when the ring needs an odd number of tiles: 196 vertices = 13 tiles = 7 + 6, and since waves w
+// and w + 4 share a SIMD every SIMD still carries 13 tiles' worth of MFMAs)
+template <int RT, int CTB, int TERMS>
 __device__ __forceinline__ void res_stack16w_body(const Stack16Args &a, int n)
 {
     static_assert(RT == 4 || RT == 7 || RT == 8, "rings of 97..128 (few contours) or 129..256 vertices");
-    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NW = 8, CTW = RT, NB = (NST * CTW) % 4 == 0 ? 4 : 2;
+    static_assert(CTB == RT || CTB == RT - 1, "the second group of waves takes as many tiles or one fewer");
+    constexpr int CBC = 8, NW = 8;
     using G = Geo<RT, CBC>;
     using S = StageGeo<RT, CBC, NW>;
     extern __shared__ __attribute__((aligned(16))) char xs[];   // chunk images 0 | 1 = 128 channels
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c16 = lane & 15, q4 = lane >> 4;
-    const int o0 = (wave & 3) * 32, j0 = (wave >> 2) * CTW;
+    const int o0 = (wave & 3) * 32, half = wave >> 2;
     const int v = a.v;
-    const long long wbs_b = 128 * 16, wts_b = 16 * wbs_b, wps_b = 9 * wts_b;
-    const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
-    auto nohook = [](int) __attribute__((always_inline)) {};
 
     for (long long nn = blockIdx.x; nn < n; nn += gridDim.x) {
         _Float16 *sn = a.state + nn * a.stride;
@@ -716,69 +787,24 @@ __device__ __forceinline__ void res_stack16w_body(const Stack16Args &a, int n)
             }
         }
         __syncthreads();
-        for (int l = 0; l < a.nlayers; ++l) {
-            f32x4 acc[2][CTW];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s[l] + o0 + 16 * i + 4 * q4);
-                const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                for (int j = 0; j < CTW; ++j)
-                    acc[i][j] = bv;
-            }
-            const char *wl = reinterpret_cast<const char *>(a.w[l]) + (long long)o0 * 16;
-            const int dil = a.dilation[l];
-#pragma unroll 1
-            for (int c = 0; c < 2; ++c)
-                mfma16_core_sw<RT, CTW, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b,
-                                                            wlane, wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, j0, nohook);
-            __syncthreads();                    // every wave has read the whole image
-            int ce = c16, qe = q4;
-            asm volatile("" : "+v"(ce), "+v"(qe));
-            _Float16 *yslot = sn + (l + 1) * a.slot;
-            const float winv = a.winv[l];
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
-                const int ob = o0 + 16 * i2 + 4 * qe;
-                const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale[l] + ob);
-                const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift[l] + ob);
-                const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-                const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
-                const int xchunk = xrow / CBC, xcbl = xrow - xchunk * CBC;
-#pragma unroll
-                for (int j = 0; j < CTW; ++j) {
-                    const int vv = (j0 + j) * 16 + ce;
-                    if (vv >= v)
-                        continue;
-                    char *q = xs + xchunk * G::BYTES + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
-                    const h4 rh = *reinterpret_cast<const h4 *>(q);
-                    const h4 rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
-                    h4 hi, lo;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float x = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
-                        x += (float)rh[i] + (float)rl[i];
-                        _Float16 xh, xl;
-                        dance::split_half(x, xh, xl);
-                        hi[i] = xh;
-                        lo[i] = xl;
-                    }
-                    *reinterpret_cast<h4 *>(q) = hi;
-                    *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
-                    _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
-                    *reinterpret_cast<h4 *>(d) = hi;
-                    *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
-                }
-            }
-            __syncthreads();                    // image = block l + 1's input
-        }
+        if (CTB != RT && half == 1)
+            res_stack16w_layers<RT, CTB, TERMS>(a, sn, xs, o0, RT, c16, q4);
+        else
+            res_stack16w_layers<RT, RT, TERMS>(a, sn, xs, o0, half * RT, c16, q4);
     }
 }
 
 template <int RT, int TERMS>
 __global__ __launch_bounds__(512) void k_res_stack16w(Stack16Args a, int n)
 {
-    res_stack16w_body<RT, TERMS>(a, n);
+    res_stack16w_body<RT, RT, TERMS>(a, n);
+}
+
+// 13 tiles (193..208 vertices, the shipped yamls' 196): 7 + 6
+template <int RT, int TERMS>
+__global__ __launch_bounds__(512) void k_res_stack16w13(Stack16Args a, int n)
+{
+    res_stack16w_body<RT, RT - 1, TERMS>(a, n);
 }
 
 // fusion (1024 -> 256, max over the ring) + row constant + prediction[0] (1280 -> 256, ReLU)
@@ -1387,10 +1413,14 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
     // CU either way, so it gets 8 waves instead of 4 (-9 % on the stack at n = 100; same products
     // and summation order as k_res_stack16s, bit-identical).  DANCE_STACK_SMALL_N = largest such n.
     static const int small_n = env_int("DANCE_STACK_SMALL_N", 256);
+    // 193..208 vertices: 13 vertex tiles as 7 + 6 instead of 14 (DANCE_STACK_ODD_SPLIT=0: 7 + 7)
+    static const int odd_split = env_int("DANCE_STACK_ODD_SPLIT", 1);
     if (rt > 4 || (rt == 4 && n <= small_n)) {                     // 129..256 vertices: 8 waves, one workgroup per CU
         int rc_ = 0;
         if (rt == 4)
             LAUNCH_ONE(k_res_stack16w, 4, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else if (rt == 7 && v > 192 && v <= 208 && odd_split)
+            LAUNCH_ONE(k_res_stack16w13, 7, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
         else if (rt == 7)
             LAUNCH_ONE(k_res_stack16w, 7, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
         else
