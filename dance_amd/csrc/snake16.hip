@@ -21,6 +21,14 @@
 // Kernels: k_conv16 (residual SnakeBlock / k=1 Conv1d), k_fuse16 (fusion + max over the ring
 // + row constant + prediction[0], the 1024-channel state read once), k_gather_head16 (gather
 // + de_location + head block).
+#ifndef DANCE_FUSE_DMA
+// 1: k_fuse16 / k_fuse16r stage their chunk images by LDS-direct loads (stage_dma, inline asm with
+// hand-placed waits) instead of registers + ds_write.  Built, bit-identical results (127 GPU
+// tests), measured same box twice: fusion kernel 0.611 / 0.613 ms through registers, 0.622 /
+// 0.624 ms with the DMA (1600 contours x 128 vertices) -- the staging registers and ds_writes
+// are not what the K loop waits for.  Off by default; -DDANCE_FUSE_DMA=1 builds it.
+#define DANCE_FUSE_DMA 0
+#endif
 #include "common.h"
 #include "mfma16.h"
 #include "p16.h"
@@ -255,6 +263,41 @@ __device__ __forceinline__ void stage_commit(const u32x4 (&reg)[(StageGeo<RT, CB
         const unsigned col = min((j % S::G::CPR) * 64 + lane, v - 1);
         *reinterpret_cast<u32x4 *>(xs + lds0 + (row * S::G::VP + col) * 16u) = reg[j];
     }
+}
+
+// The same staging without registers: global_load_lds_dwordx4 moves 16 B per lane straight into
+// LDS (destination = M0 base + lane * 16: a wave-instruction fills 64 consecutive words of an
+// image row).  Written as inline asm on purpose: through the builtin the compiler cannot tell the
+// image being filled from the one being read and puts s_waitcnt vmcnt(0) in front of the MFMA
+// loop's ds_reads, which also drains the weight prefetch (measured: slower than registers).  The
+// asm is invisible to its counter bookkeeping -- its own waits for the weight loads stay correct
+// (vmcnt retires in order, they only ever wait for more) -- so the CALLER must issue
+// s_waitcnt vmcnt(0) before the barrier that publishes the image (stage_dma_wait).
+//   lds_dst: byte offset of the image inside the workgroup's LDS (wave-uniform)
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_dma(int jlo, int jhi, const char *src, unsigned lds_dst, int v, int wave,
+                                          int lane, int vs)
+{
+    using S = StageGeo<RT, CBC, NW>;
+#pragma unroll
+    for (int j = 0; j < S::N; ++j)
+        if (j >= jlo && j < jhi) {
+            const int row = wave + NW * (j / S::G::CPR);
+            const int plane = row >= CBC ? 1 : 0, cbl = row - plane * CBC;
+            const int col0 = (j % S::G::CPR) * 64;
+            const unsigned col = min(col0 + lane, v - 1);
+            const char *g = src + (plane * 256ll + cbl * 16ll) * vs + col * 16u;
+            const unsigned l = __builtin_amdgcn_readfirstlane(lds_dst + (unsigned)(row * S::G::VP + col0) * 16u);
+            // an odd number of 32-wide tiles: the last pass covers half a row, the other lanes
+            // would land in the next row
+            if (RT % 2 == 0 || col0 + lane < RT * 32)
+                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(l) : "memory");
+        }
+}
+
+__device__ __forceinline__ void stage_dma_wait()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 
@@ -864,10 +907,16 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
         return reinterpret_cast<const char *>(a.x + m * a.x_stride + c * a.x_slot_stride) + v0 * 16;
     };
 
-    u32x4 sreg[S::N];
     long long nn = blockIdx.x;
+#if DANCE_FUSE_DMA
+    const unsigned lds_base = __builtin_amdgcn_groupstaticsize();   // the dynamic segment follows the static one
+    stage_dma<RT, CBC, NW>(0, S::N, chunk_src(nn, 0), lds_base, v, wave, lane, vs);
+    stage_dma_wait();
+#else
+    u32x4 sreg[S::N];
     stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane, vs);
     stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
+#endif
     __syncthreads();
 
     unsigned pl[RT];                            // this lane's word in each vertex tile (no ring shift: k = 1)
@@ -911,7 +960,12 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
                     // next step's weights: the sequence runs on linearly into the next chunk
                     if (s + 1 < NST || !last)
                         F_LOAD_A((s + 1) % 2, wchunk + (s + 1) * wstep_b);
+#if DANCE_FUSE_DMA
+                    if (has_next)
+                        stage_dma<RT, CBC, NW>(s * S::N / NST, (s + 1) * S::N / NST, ssrc, lds_base + nxt, v, wave, lane, vs);
+#else
                     stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane, vs);
+#endif
                 }
                 if constexpr (q + 1 < NT)
                     F_LOAD_B(q + 1);
@@ -926,8 +980,12 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
                 acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2][1], bh[q % 2], acc[1][rt], 0, 0, 0);
             });
 #undef F_LOAD_B
+#if DANCE_FUSE_DMA
+            stage_dma_wait();
+#else
             if (has_next)
                 stage_commit<RT, CBC, NW>(sreg, xs, nxt, v, wave, lane);
+#endif
             __syncthreads();
         }
 #undef F_LOAD_A
