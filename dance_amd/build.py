@@ -30,6 +30,7 @@ SOURCES = [
     ("raster.hip", ["-ffp-contract=off"]),
     ("attender.hip", []),
     ("fcose.hip", ["-ffp-contract=off"]),
+    ("targets.hip", ["-ffp-contract=off"]),
 ]
 HEADERS = ["common.h", "sampling.h", "p16.h", "mfma16.h", os.path.join("..", "..", "include", "dance_hip.h")]
 

@@ -215,6 +215,41 @@ int dance_fcose_fill(const dance_fcose_level *levels, int n_levels, const int32_
                      float *scores, int64_t *classes, float *out_loc, float *boxes, float *extpts,
                      void *stream);
 
+/* --------------------------------- training-side target matching --- */
+/* The NumPy half of RefineNet.compute_targets_for_polys, ONE WORKGROUP PER INSTANCE.  Float
+ * results are float64 (what NumPy 2.2 promotes the reference's lines to) and bit-identical to the
+ * reference's on the same inputs; status (n) i32: 0 ok, 1 = the reference raises / falls back
+ * there, 2 = sizes outside the kernels' limits (2048 polygon vertices / contour points).
+ *
+ * dance_uniform_sample: reference RefineNet.uniform_sample (snake_head.py:661-725).  polys
+ *   (sum p, 2) f32 with poly_off (n + 1) i32; newpnum (n) i32; out (sum newpnum, 2) f64 at
+ *   out_off (n + 1) i64 (points).  p > newpnum: the shortest edges' start points dropped (the
+ *   kept float32 rows, widened); else points spread over the edges in proportion to their length.
+ *   Ties in edge length go to the lowest index (the reference's np.argsort is unstable there).
+ * dance_dense_targets: uniform_sample(cnt, p * m), rolled so that the point nearest first[n]
+ *   (f32 x, y: the initial contour's vertex 0) leads, every p-th point kept (snake_head.py:
+ *   1134-1144): out (n, m, 2) f64; the p * m points are never stored.
+ * dance_uniform_sample_1d: reference RefineNet.uniform_sample_1d (snake_head.py:728-762): open
+ *   poly-lines pts (sum nn, 2) f64 at off (n + 1) i32 -> new_n[n] points each.
+ * dance_aux_extreme_points: reference get_aux_extreme_points (core/modeling/fcose/utils.py:
+ *   94-189): pts (n, num_points, 2) f64 closed contours -> reordered (same shape), ext_idx
+ *   (n, cap) i64 sorted unique indices, count (n).
+ * dance_segment_matching: reference RefineNet.single_uniform_segment_matching (snake_head.py:
+ *   1265-1384, INITIAL = octagon) with its fall-back reorder_perloss (1520-1540): dense
+ *   (n, v * up_rate, 2) f64, sampled (n, v, 2) f32, edge_idx (n, e_num) i64 -> out (n, v, 2) f64;
+ *   status 1 = the fall-back was taken. */
+int dance_uniform_sample(const float *polys, const int32_t *poly_off, const int32_t *newpnum,
+                         const int64_t *out_off, double *out, int32_t *status, int n, void *stream);
+int dance_dense_targets(const float *polys, const int32_t *poly_off, const float *first, int m,
+                        double *out, int32_t *status, int n, void *stream);
+int dance_uniform_sample_1d(const double *pts, const int32_t *off, const int32_t *new_n,
+                            const int64_t *out_off, double *out, int32_t *status, int n, void *stream);
+int dance_aux_extreme_points(const double *pts, double *reordered, int64_t *ext_idx, int32_t *count,
+                             int32_t *status, int n, int num_points, int cap, void *stream);
+int dance_segment_matching(const double *dense, const float *sampled, const int64_t *edge_idx,
+                           double *out, int32_t *status, int n, int v, int up_rate, int e_num,
+                           void *stream);
+
 /* ------------------------------------------------- contour initialisation (a11-a15) - */
 enum {
     DANCE_POLY_RAW = 0,      /* src = polygons (n,e,2)                                  */

@@ -16,10 +16,11 @@ import os
 import sys
 
 import numpy as np
+from types import SimpleNamespace as NS
 import torch
 
 from dance_amd import synthetic
-from oracle import extreme_utils_ref, ref_loader, snake_ref
+from oracle import extreme_utils_ref, ref_loader, snake_ref, targets_ref
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 WEIGHT_SEED = 1234
@@ -501,6 +502,82 @@ def gen_fcose():
     _save("g11_fcose", **out)
 
 
+# ------------------------------------------------------------------------------- G12
+def target_polygons():
+    """Clockwise (image coordinates, y down) star-shaped ground-truth polygons, float32."""
+    out = []
+    for seed, p, cx, cy, r0 in [(1, 5, 300, 200, 80), (2, 17, 310.5, 220.25, 60), (3, 60, 500, 400, 150),
+                                (4, 200, 640, 380, 300), (5, 9, 100, 90, 20), (6, 33, 900, 600, 110),
+                                (7, 128, 256, 256, 200), (8, 4, 50, 40, 30)]:
+        g = np.random.default_rng(seed)
+        ang = np.sort(g.random(p) * 2 * np.pi)
+        rad = r0 * (0.55 + 0.45 * g.random(p))
+        out.append(np.stack([cx + rad * np.cos(ang), cy + 0.8 * rad * np.sin(ang)], 1).astype(np.float32))
+    return out
+
+
+def gen_targets(sh):
+    """The NumPy half of the training-side target matching: the reference's own
+    uniform_sample / uniform_sample_1d / get_aux_extreme_points / single_uniform_segment_matching
+    on seeded polygons; oracle/targets_ref.py must reproduce indices AND float64 points exactly."""
+    fu = ref_loader.load_fcose_utils()
+    R = sh.RefineNet
+    out, v, up = {}, 32, 5
+    polys = target_polygons()
+    out["n_polys"] = np.int64(len(polys))
+    import logging
+    me = NS(initial="octagon", num_sampling=v, _logger=logging.getLogger("gen_golden"),
+            uniform_sample_1d=R.uniform_sample_1d)
+    me.reorder_perloss = lambda a, b: R.reorder_perloss(me, a, b)
+    for i, cnt in enumerate(polys):
+        p = len(cnt)
+        out["poly%d" % i] = cnt
+        # uniform_sample: remove branch, small add, the size the training path asks for
+        for tag, newp in (("rm", max(3, p - 3)), ("eq", p), ("add", 4 * p + 3), ("big", p * v * up)):
+            want = R.uniform_sample(cnt, newp)
+            got = targets_ref.uniform_sample(cnt, newp)
+            assert want.dtype == got.dtype and np.array_equal(want, got), ("uniform_sample", i, tag)
+            if tag != "big":
+                out["us_%s_%d" % (tag, i)] = want
+                out["us_%s_n%d" % (tag, i)] = np.int64(newp)
+        dense_all = R.uniform_sample(cnt, p * v * up)
+        # initial contour: octagon of the polygon's extreme points (snake_head.py:1020-1045)
+        ex = np.stack([cnt[np.argmin(cnt[:, 1])], cnt[np.argmin(cnt[:, 0])], cnt[np.argmax(cnt[:, 1])],
+                       cnt[np.argmax(cnt[:, 0])]])
+        octs, eidx = snake_ref.get_octagon(torch.from_numpy(ex)[None], v)
+        sampled = octs[0].numpy()
+        eidx = eidx[0].numpy()
+        tt = int(np.argmin(np.power(dense_all - sampled[0], 2).sum(axis=1)))     # snake_head.py:1139-1144
+        dense = np.roll(dense_all, -tt, axis=0)[::p]
+        assert dense.shape == (v * up, 2)
+        out["dense%d" % i], out["sampled%d" % i], out["edge_idx%d" % i] = dense, sampled, eidx
+        # uniform_sample_1d on arcs of the dense contour
+        for k, (a, b, m) in enumerate([(0, 40, 7), (10, 17, 6), (3, 90, 30), (0, v * up, v), (5, 7, 1), (20, 60, 64)]):
+            want = R.uniform_sample_1d(dense[a:b], m)
+            got = targets_ref.uniform_sample_1d(dense[a:b], m)
+            assert np.array_equal(want, got), ("uniform_sample_1d", i, k)
+            out["s1d_%d_%d" % (i, k)] = want
+            out["s1d_arg_%d_%d" % (i, k)] = np.array([a, b, m], np.int64)
+        # get_aux_extreme_points
+        re_w, ext_w = fu.get_aux_extreme_points(dense)
+        re_g, ext_g = targets_ref.get_aux_extreme_points(dense)
+        assert np.array_equal(re_w, re_g) and np.array_equal(ext_w, ext_g), ("aux", i)
+        out["aux_pts%d" % i], out["aux_idx%d" % i] = re_w, ext_w
+        # single_uniform_segment_matching (INITIAL = octagon, NEW_MATCHING)
+        want = R.single_uniform_segment_matching(me, dense.copy(), sampled, eidx, up)
+        got, status = targets_ref.single_uniform_segment_matching(dense, sampled, eidx, up, v)
+        assert status == 0 and np.array_equal(want, got), ("segment_matching", i)
+        out["match%d" % i] = want
+    # the fall-back of the matching (a collapsed ground truth: every arc has zero length)
+    flat = np.tile(np.array([[10.0, 20.0]]), (v * up, 1))
+    want = R.single_uniform_segment_matching(me, flat.copy(), sampled, eidx, up)
+    got, status = targets_ref.single_uniform_segment_matching(flat, sampled, eidx, up, v)
+    assert status == 1 and np.array_equal(want, got)
+    out["match_flat"] = want
+    out["v"], out["up"] = np.int64(v), np.int64(up)
+    _save("g12_targets", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -511,7 +588,8 @@ def main():
              "blocks": lambda: gen_blocks(sh), "snakenet": lambda: gen_snakenet(sh),
              "dance": lambda: gen_dance(sh), "dsnake": lambda: gen_dsnake(dh),
              "upsample2x": lambda: gen_upsample2x(sh), "bottom_out": lambda: gen_bottom_out(sh),
-             "attender": gen_attender, "edge_head": gen_edge_head, "fcose": gen_fcose}
+             "attender": gen_attender, "edge_head": gen_edge_head, "fcose": gen_fcose,
+             "targets": lambda: gen_targets(sh)}
     # `python -m oracle.gen_golden attender ...` regenerates only the named fixtures (floating-
     # point fixtures move in the last bits with the host CPU's kernels: keep the committed ones)
     for name in (sys.argv[1:] or list(steps)):

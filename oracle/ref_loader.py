@@ -114,6 +114,19 @@ def load_reference():
     return _loaded["snake"], _loaded["dsnake"]
 
 
+def load_fcose_utils():
+    """The reference's core/modeling/fcose/utils.py (get_aux_extreme_points, get_extreme_points:
+    pure NumPy), loaded by path; its detectron2 / pycocotools imports get placeholders."""
+    if "fcose_utils" in _loaded:
+        return _loaded["fcose_utils"]
+    load_reference()
+    _module("detectron2.structures")
+    _module("detectron2.structures.boxes", Boxes=_TensorBox)
+    _module("core.structures.points_set", ExtremePoints=_TensorBox)
+    _loaded["fcose_utils"] = _load("_dance_ref_fcose_utils", REF + "/core/modeling/fcose/utils.py")
+    return _loaded["fcose_utils"]
+
+
 def dance_cfg(num_sampling=196, initial="box", num_convs=2, attention=True,
               individual_scale=True, de_loc_type="derange", convs_dim=256):
     """configs/Dance_R_50_3x.yaml on top of core/config/defaults.py -- only the keys
