@@ -91,6 +91,7 @@ SIGNATURES = {
     "dance_uniform_sample_1d": (c_int, [P, P, P, P, P, P, c_int, P]),
     "dance_aux_extreme_points": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
     "dance_segment_matching": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_multisegment_matching": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_uniform_upsample": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P]),
     "dance_nchw_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_gather_features": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -544,6 +544,36 @@ __global__ __launch_bounds__(NT) void k_aux_extreme_points(const double *pts_all
     }
 }
 
+// the reference's fall-back of both matchings: the cyclic shift of dense[::up] nearest the contour
+// (summed squared distance, first minimum), snake_head.py:1378-1382 / 1492-1496, 1520-1540
+__device__ void fallback_reorder(const double *dense, const float *sampled, double *out, int v, int up, MinIdx *red)
+{
+    const int t = threadIdx.x;
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int s = t; s < v; s += NT) {
+        double tot = 0.0;
+        for (int i = 0; i < v; ++i) {
+            int k = s + i;
+            k = k >= v ? k - v : k;
+            const double dx = dense[2ll * k * up] - (double)sampled[2 * i];
+            const double dy = dense[2ll * k * up + 1] - (double)sampled[2 * i + 1];
+            tot = tot + (dx * dx + dy * dy);
+        }
+        if (better(tot, s, bd, bi)) {
+            bd = tot;
+            bi = s;
+        }
+    }
+    const int sft = block_argmin(bd, bi, red).i;
+    for (int i = t; i < v; i += NT) {
+        int k = sft + i;
+        k = k >= v ? k - v : k;
+        out[2 * i] = dense[2ll * k * up];
+        out[2 * i + 1] = dense[2ll * k * up + 1];
+    }
+}
+
 // ------------------------------------------------------------------ segment matching
 __global__ __launch_bounds__(NT) void k_segment_matching(const double *dense_all, const float *sampled_all,
                                                          const long long *edge_idx_all, double *out_all, int *status,
@@ -640,31 +670,154 @@ __global__ __launch_bounds__(NT) void k_segment_matching(const double *dense_all
             status[n] = 0;
         return;
     }
-    // the reference's fall-back: the cyclic shift of dense[::up] nearest the contour (summed
-    // squared distance, first minimum), snake_head.py:1378-1382, 1520-1540
-    double bd = INFINITY;
-    int bi = 0x7fffffff;
-    for (int s = t; s < v; s += NT) {
-        double tot = 0.0;
-        for (int i = 0; i < v; ++i) {
-            int k = s + i;
-            k = k >= v ? k - v : k;
-            const double dx = dense[2ll * k * up] - (double)sampled[2 * i];
-            const double dy = dense[2ll * k * up + 1] - (double)sampled[2 * i + 1];
-            tot = tot + (dx * dx + dy * dy);
+    fallback_reorder(dense, sampled, out, v, up, red);
+    if (t == 0)
+        status[n] = 1;
+}
+
+// RefineNet.single_uniform_multisegment_matching (snake_head.py:1386-1498), the form the shipped
+// configuration (INITIAL = box, NEW_MATCHING) runs after get_aux_extreme_points, together with the
+// roll of the initial contour that precedes it (1150-1155): the contour is rolled to start at the
+// vertex nearest dense[0]; the auxiliary extreme points (indices into dense, sorted, first = 0)
+// are matched to their nearest contour vertices; every arc between consecutive ones is resampled
+// to the contour's vertex count on that arc.  k (ext_count) >= 2.
+__global__ __launch_bounds__(NT) void k_multisegment_matching(const double *dense_all, const float *sampled_all,
+                                                              const long long *ext_all, const int *ext_count,
+                                                              float *rolled_all, double *out_all, int *status,
+                                                              int v, int up, int cap)
+{
+    constexpr int MAXK = 65;
+    __shared__ double start[MAXP], seg[MAXP];
+    __shared__ MinIdx red[NT];
+    __shared__ float roll[2 * MAXP];
+    __shared__ int mn[MAXK + 1], aext[MAXK + 1], flag, okflag;
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int big = v * up, k = ext_count[n];
+    const double *dense = dense_all + 2ll * n * big;
+    const float *sampled = sampled_all + 2ll * n * v;
+    const long long *ext = ext_all + (long long)n * cap;
+    double *out = out_all + 2ll * n * v;
+    float *rolled = rolled_all + 2ll * n * v;
+    if (k < 2 || k > MAXK - 1 || k > cap) {
+        if (t == 0)
+            status[n] = 2;
+        return;
+    }
+    {   // roll the contour: vertex nearest dense[0] first (float32 - float64 -> float64)
+        double bd = INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = t; i < v; i += NT) {
+            const double dx = (double)sampled[2 * i] - dense[0], dy = (double)sampled[2 * i + 1] - dense[1];
+            const double d = dx * dx + dy * dy;
+            if (better(d, i, bd, bi)) {
+                bd = d;
+                bi = i;
+            }
         }
-        if (better(tot, s, bd, bi)) {
-            bd = tot;
-            bi = s;
+        const int sft = block_argmin(bd, bi, red).i;
+        for (int i = t; i < v; i += NT) {
+            int s = i + sft;
+            s = s >= v ? s - v : s;
+            roll[2 * i] = sampled[2 * s];
+            roll[2 * i + 1] = sampled[2 * s + 1];
+            rolled[2 * i] = sampled[2 * s];
+            rolled[2 * i + 1] = sampled[2 * s + 1];
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < k; ++j) {
+        const int m = (int)ext[j];
+        const double cx = dense[2 * m], cy = dense[2 * m + 1];
+        double bd = INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = t; i < v; i += NT) {
+            const double dx = cx - (double)roll[2 * i], dy = cy - (double)roll[2 * i + 1];
+            const double d = dx * dx + dy * dy;
+            if (better(d, i, bd, bi)) {
+                bd = d;
+                bi = i;
+            }
+        }
+        const int e = block_argmin(bd, bi, red).i;
+        if (t == 0) {
+            aext[j] = e;
+            mn[j] = m;
         }
     }
-    const int sft = block_argmin(bd, bi, red).i;
-    for (int i = t; i < v; i += NT) {
-        int k = sft + i;
-        k = k >= v ? k - v : k;
-        out[2 * i] = dense[2ll * k * up];
-        out[2 * i + 1] = dense[2ll * k * up + 1];
+    if (t == 0) {
+        if (aext[0] != 0)
+            aext[0] = 0;
+        if (aext[k - 1] < aext[1])
+            aext[k - 1] = v - 2;
+        // np.sort(ext_idx), then the bound appended and both lists sorted again (1406-1434)
+        for (int a = 1; a < k; ++a)
+            for (int c = a; c > 0 && aext[c - 1] > aext[c]; --c) {
+                const int x = aext[c - 1];
+                aext[c - 1] = aext[c];
+                aext[c] = x;
+            }
+        aext[k] = v;
+        mn[k] = big;
+        if (mn[k] < mn[1])
+            mn[k] = big - 2;
+        if (mn[0] != 0)
+            mn[0] = 0;
+        for (int a = 1; a <= k; ++a) {
+            for (int c = a; c > 0 && aext[c - 1] > aext[c]; --c) {
+                const int x = aext[c - 1];
+                aext[c - 1] = aext[c];
+                aext[c] = x;
+            }
+            for (int c = a; c > 0 && mn[c - 1] > mn[c]; --c) {
+                const int x = mn[c - 1];
+                mn[c - 1] = mn[c];
+                mn[c] = x;
+            }
+        }
+        if (mn[k - 1] == big - 1) {
+            mn[k - 1] = big - 3;
+            mn[k] = big - 2;
+        }
+        if (mn[k] == big - 1) {
+            mn[k] -= 1;
+            mn[k - 1] -= 1;
+        }
+        okflag = 1;
     }
+    __syncthreads();
+    int written = 0;
+    for (int i = 0; i < k; ++i) {
+        const int cnt = aext[i + 1] - aext[i];
+        if (cnt == 0)
+            continue;
+        if (t == 0 && mn[i + 1] - mn[i] <= 0)
+            mn[i + 1] = mn[i] + 1;
+        __syncthreads();
+        const int a0 = mn[i];
+        const bool closing = i == k - 1;
+        int len = closing ? big - a0 + 1 : mn[i + 1] + 1 - a0;
+        if (!closing && a0 + len > big)
+            len = big - a0;
+        if (len < 0)
+            len = 0;
+        bool ok = len >= 1 && written + cnt <= v && len <= MAXP;
+        if (ok)
+            ok = sample_1d(dense + 2ll * a0, len, closing ? dense : nullptr, cnt, out + 2 * written, start, seg, &flag);
+        if (!ok) {
+            if (t == 0)
+                okflag = 0;
+            break;
+        }
+        written += cnt;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (okflag && written == v) {
+        if (t == 0)
+            status[n] = 0;
+        return;
+    }
+    fallback_reorder(dense, roll, out, v, up, red);
     if (t == 0)
         status[n] = 1;
 }
@@ -729,5 +882,18 @@ extern "C" int dance_segment_matching(const double *dense, const float *sampled,
     DANCE_REQUIRE(dense && sampled && edge_idx && out && status);
     hipLaunchKernelGGL(k_segment_matching, dim3(n), dim3(NT), 0, (hipStream_t)stream, dense, sampled,
                        (const long long *)edge_idx, out, status, v, up_rate, e_num);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_multisegment_matching(const double *dense, const float *sampled, const int64_t *ext_idx,
+                                           const int32_t *ext_count, float *rolled, double *out, int32_t *status,
+                                           int n, int v, int up_rate, int cap, void *stream)
+{
+    DANCE_REQUIRE(n >= 0 && v >= 4 && up_rate >= 1 && (long long)v * up_rate + 1 <= MAXP && cap >= 2);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(dense && sampled && ext_idx && ext_count && rolled && out && status);
+    hipLaunchKernelGGL(k_multisegment_matching, dim3(n), dim3(NT), 0, (hipStream_t)stream, dense, sampled,
+                       (const long long *)ext_idx, ext_count, rolled, out, status, v, up_rate, cap);
     return launch_check(__func__);
 }

@@ -111,6 +111,7 @@ def get_aux_extreme_points(contours, cap=64):
     if bool((status != 0).any()):
         raise RuntimeError("get_aux_extreme_points: more than %d auxiliary extreme points" % cap)
     c = count.tolist()
+    re.ext_idx_padded, re.ext_count = ext, count                 # the batch form the matching takes
     return re, [ext[i, :c[i]] for i in range(n)]
 
 
@@ -134,3 +135,33 @@ def single_uniform_segment_matching(dense_targets_, sampled_pts, edge_idx, up_ra
         check(lib().dance_segment_matching(ptr(dense), ptr(sampled), ptr(eidx), ptr(out), ptr(status), n, v,
                                            up_rate, eidx.size(1), current_stream()), "segment_matching")
     return out, status
+
+
+def single_uniform_multisegment_matching(dense_reordered, sampled_pts, ext_idx, ext_count, up_rate):
+    """RefineNet.single_uniform_multisegment_matching (snake_head.py:1386-1498, the shipped
+    INITIAL = "box" + NEW_MATCHING form) for a batch, including the roll of the initial contour
+    that precedes it (1150-1155).  dense_reordered (n, V * up_rate, 2) float64 and ext_idx
+    (n, cap) int64 / ext_count (n) int32 as get_aux_extreme_points leaves them (`.ext_idx_padded`,
+    `.ext_count` of its first result); sampled_pts (n, V, 2) float32.
+    Returns (rolled contour (n, V, 2) float32, targets (n, V, 2) float64, status (n))."""
+    dense = torch.as_tensor(dense_reordered)
+    if not dense.is_cuda:
+        raise RuntimeError("single_uniform_multisegment_matching: CUDA tensors expected")
+    dense = dense.to(torch.float64).contiguous()
+    sampled = torch.as_tensor(sampled_pts).to(dense.device, torch.float32).contiguous()
+    ext = torch.as_tensor(ext_idx).to(dense.device, torch.int64).contiguous()
+    cnt = torch.as_tensor(ext_count).to(dense.device, torch.int32).contiguous()
+    n, v, _ = sampled.shape
+    if dense.shape != (n, v * up_rate, 2) or ext.dim() != 2 or ext.size(0) != n or cnt.shape != (n,):
+        raise RuntimeError("single_uniform_multisegment_matching: shapes do not match")
+    rolled = torch.empty_like(sampled)
+    out = torch.empty((n, v, 2), dtype=torch.float64, device=dense.device)
+    status = torch.zeros(n, dtype=torch.int32, device=dense.device)
+    with torch.cuda.device(dense.device):
+        check(lib().dance_multisegment_matching(ptr(dense), ptr(sampled), ptr(ext), ptr(cnt), ptr(rolled), ptr(out),
+                                                ptr(status), n, v, up_rate, ext.size(1), current_stream()),
+              "multisegment_matching")
+    if bool((status == 2).any()):
+        raise RuntimeError("single_uniform_multisegment_matching: an instance has fewer than 2 (the reference "
+                           "fails there too) or more than 64 auxiliary extreme points")
+    return rolled, out, status

@@ -237,7 +237,14 @@ int dance_fcose_fill(const dance_fcose_level *levels, int n_levels, const int32_
  * dance_segment_matching: reference RefineNet.single_uniform_segment_matching (snake_head.py:
  *   1265-1384, INITIAL = octagon) with its fall-back reorder_perloss (1520-1540): dense
  *   (n, v * up_rate, 2) f64, sampled (n, v, 2) f32, edge_idx (n, e_num) i64 -> out (n, v, 2) f64;
- *   status 1 = the fall-back was taken. */
+ *   status 1 = the fall-back was taken.
+ * dance_multisegment_matching: reference RefineNet.single_uniform_multisegment_matching
+ *   (snake_head.py:1386-1498, the shipped INITIAL = box + NEW_MATCHING form) together with the
+ *   roll of the initial contour before it (1150-1155): dense (n, v * up_rate, 2) f64 = the
+ *   reordered contour of dance_aux_extreme_points, ext_idx (n, cap) i64 / ext_count (n) its
+ *   indices; sampled (n, v, 2) f32 -> rolled (n, v, 2) f32 (starts at the vertex nearest
+ *   dense[0]) and out (n, v, 2) f64; status 1 = fall-back, 2 = fewer than 2 or more than 64
+ *   indices (the reference fails on fewer than 2). */
 int dance_uniform_sample(const float *polys, const int32_t *poly_off, const int32_t *newpnum,
                          const int64_t *out_off, double *out, int32_t *status, int n, void *stream);
 int dance_dense_targets(const float *polys, const int32_t *poly_off, const float *first, int m,
@@ -249,6 +256,9 @@ int dance_aux_extreme_points(const double *pts, double *reordered, int64_t *ext_
 int dance_segment_matching(const double *dense, const float *sampled, const int64_t *edge_idx,
                            double *out, int32_t *status, int n, int v, int up_rate, int e_num,
                            void *stream);
+int dance_multisegment_matching(const double *dense, const float *sampled, const int64_t *ext_idx,
+                                const int32_t *ext_count, float *rolled, double *out, int32_t *status,
+                                int n, int v, int up_rate, int cap, void *stream);
 
 /* ------------------------------------------------- contour initialisation (a11-a15) - */
 enum {

@@ -568,6 +568,20 @@ def gen_targets(sh):
         got, status = targets_ref.single_uniform_segment_matching(dense, sampled, eidx, up, v)
         assert status == 0 and np.array_equal(want, got), ("segment_matching", i)
         out["match%d" % i] = want
+        # the shipped configuration's form (INITIAL = box): box contour, rolled to the first target
+        # of the re-ordered dense contour, then single_uniform_multisegment_matching
+        box = torch.tensor([[float(cnt[:, 0].min()), float(cnt[:, 1].min()), float(cnt[:, 0].max()),
+                             float(cnt[:, 1].max())]])
+        bpts = snake_ref.uniform_upsample(snake_ref.box_polygon(box)[None], v)[0][0].numpy()
+        tt = int(np.argmin(np.power(bpts - re_w[0], 2).sum(axis=1)))                 # snake_head.py:1150-1155
+        rolled = np.roll(bpts, -tt, axis=0)
+        assert np.array_equal(rolled, targets_ref.roll_to_first_target(bpts, re_w))
+        me.initial = "box"
+        want = R.single_uniform_multisegment_matching(me, re_w.copy(), rolled, ext_w.copy(), up)
+        me.initial = "octagon"
+        got, status = targets_ref.single_uniform_multisegment_matching(re_w, rolled, ext_w, up, v)
+        assert status == 0 and np.array_equal(want, got), ("multisegment_matching", i)
+        out["box_pts%d" % i], out["box_rolled%d" % i], out["mmatch%d" % i] = bpts, rolled, want
     # the fall-back of the matching (a collapsed ground truth: every arc has zero length)
     flat = np.tile(np.array([[10.0, 20.0]]), (v * up, 1))
     want = R.single_uniform_segment_matching(me, flat.copy(), sampled, eidx, up)

@@ -7,6 +7,7 @@ CPU restatement of the NumPy half of the reference's training-side target matchi
   uniform_sample_1d               snake_head.py:728-762
   get_aux_extreme_points          core/modeling/fcose/utils.py:94-189
   single_uniform_segment_matching snake_head.py:1265-1384 (INITIAL = "octagon" form)
+  single_uniform_multisegment_matching snake_head.py:1386-1498 (INITIAL = "box", the shipped form)
   reorder_perloss                 snake_head.py:1520-1540 (the fall-back of the matching)
 
 Pinned: oracle/gen_golden.py `targets` runs the reference's own functions (loaded from
@@ -278,6 +279,68 @@ def single_uniform_segment_matching(dense, sampled, edge_idx, up_rate, num_sampl
         else:
             arc = dense[mn[i]:mn[i + 1] + 1]
         if len(arc) < 2 and cnt != 1:                        # the reference's indexing raises here
+            ok = False
+            break
+        s = uniform_sample_1d(arc, cnt)
+        if s is None:
+            ok = False
+            break
+        segs.append(s)
+    if ok:
+        out = np.concatenate(segs, axis=0)
+        if len(out) == v:
+            return out, 0
+    return reorder_perloss(dense[::up_rate], sampled)[0], 1
+
+
+def roll_to_first_target(sampled, dense):
+    """The initial contour rolled to start at the vertex nearest the first dense target
+    (snake_head.py:1150-1155).  sampled (V, 2) float32."""
+    d0 = np.asarray(dense[0], np.float64)
+    tt = _argmin_sq([s.astype(np.float64) for s in sampled], d0)
+    return np.roll(sampled, -tt, axis=0)
+
+
+def single_uniform_multisegment_matching(dense, sampled, ext_idx, up_rate, num_sampling):
+    """The matching of the shipped configuration (INITIAL = box, NEW_MATCHING): ext_idx = the
+    auxiliary extreme points' indices into dense (sorted, unique, first 0), matched to their
+    nearest vertices of the (already rolled) contour; every arc between consecutive ones is
+    resampled to the contour's vertex count on it.  Returns (targets (V, 2) float64, status) as
+    single_uniform_segment_matching; snake_head.py:1386-1498."""
+    dense = np.asarray(dense, np.float64)
+    v, big = num_sampling, num_sampling * up_rate
+    mn = [int(e) for e in ext_idx]
+    k = len(mn)
+    samp64 = [s.astype(np.float64) for s in sampled]
+    ext = [_argmin_sq(samp64, dense[m]) for m in mn]
+    if ext[0] != 0:
+        ext[0] = 0
+    if ext[-1] < ext[1]:
+        ext[-1] = v - 2
+    aug_ext = sorted(sorted(ext) + [v])
+    mn = mn + [big]
+    if mn[-1] < mn[1]:
+        mn[-1] = big - 2
+    if mn[0] != 0:
+        mn[0] = 0
+    mn.sort()
+    if mn[-2] == big - 1:
+        mn[-2], mn[-1] = big - 3, big - 2
+    if mn[-1] == big - 1:
+        mn[-1] -= 1
+        mn[-2] -= 1
+    segs, ok = [], True
+    for i in range(k):
+        cnt = aug_ext[i + 1] - aug_ext[i]
+        if cnt == 0:
+            continue
+        if mn[i + 1] - mn[i] <= 0:
+            mn[i + 1] = mn[i] + 1
+        if i == k - 1:
+            arc = np.concatenate([dense[mn[i]:], dense[:1]], axis=0)
+        else:
+            arc = dense[mn[i]:mn[i + 1] + 1]
+        if len(arc) < 2 and cnt != 1:
             ok = False
             break
         s = uniform_sample_1d(arc, cnt)

@@ -48,6 +48,14 @@ def test_dense_targets_and_matching_golden(device):
     assert status.tolist() == [0] * n
     for i in range(n):
         assert np.array_equal(out[i].cpu().numpy(), g["match%d" % i])
+    # the shipped configuration's form: box contour rolled to the first target + multisegment matching
+    box = np.stack([g["box_pts%d" % i] for i in range(n)])
+    rolled, mout, mstatus = targets.single_uniform_multisegment_matching(re, torch.from_numpy(box), re.ext_idx_padded,
+                                                                         re.ext_count, up)
+    assert mstatus.tolist() == [0] * n
+    for i in range(n):
+        assert np.array_equal(rolled[i].cpu().numpy(), g["box_rolled%d" % i])
+        assert np.array_equal(mout[i].cpu().numpy(), g["mmatch%d" % i])
     # the reference's fall-back (collapsed ground truth)
     flat = torch.from_numpy(np.tile(np.array([[10.0, 20.0]]), (1, v * up, 1))).to(device)
     out, status = targets.single_uniform_segment_matching(flat, torch.from_numpy(sampled[-1:]),
@@ -105,6 +113,17 @@ def test_whole_chain_vs_oracle_random(device, v):
         assert np.array_equal(re[i].cpu().numpy(), re_w) and np.array_equal(ext[i].cpu().numpy(), ext_w), i
         m_w, st_w = targets_ref.single_uniform_segment_matching(want, sampled[i], eidx[i].numpy(), up, v)
         assert int(status[i]) == st_w and np.array_equal(out[i].cpu().numpy(), m_w), i
+    # box contours through the multisegment form (INITIAL = box)
+    boxes = torch.tensor([[float(c[:, 0].min()), float(c[:, 1].min()), float(c[:, 0].max()), float(c[:, 1].max())]
+                          for c in polys])
+    bpts = snake_ref.uniform_upsample(snake_ref.box_polygon(boxes)[None], v)[0]
+    rolled, mout, mstatus = targets.single_uniform_multisegment_matching(re, bpts, re.ext_idx_padded, re.ext_count, up)
+    for i in range(n):
+        re_w, ext_w = re[i].cpu().numpy(), ext[i].cpu().numpy()
+        r_w = targets_ref.roll_to_first_target(bpts[i].numpy(), re_w)
+        assert np.array_equal(rolled[i].cpu().numpy(), r_w), i
+        m_w, st_w = targets_ref.single_uniform_multisegment_matching(re_w, r_w, ext_w, up, v)
+        assert int(mstatus[i]) == st_w and np.array_equal(mout[i].cpu().numpy(), m_w), i
 
 
 def test_uniform_sample_random_vs_oracle(device):
