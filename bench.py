@@ -568,6 +568,68 @@ def main():
                                  "bounds; the stock sequence syncs once per image and level in nonzero())"}
             del fc_logits, fc_ctr, fc_reg, fc_ext, fc_fields
 
+    target_fig = None
+    if rank == 0 and extras:
+        # training-side target matching, NumPy half: the shipped configuration's
+        # chain (dense targets -> auxiliary extreme points -> contour roll + multisegment matching,
+        # snake_head.py:1134-1162) for 512 ground-truth polygons, one workgroup per instance
+        import numpy as np
+        from dance_amd import targets
+        from dance_amd._lib import check, current_stream, lib, ptr
+        tn, tup = 512, 5
+        rng = np.random.default_rng(9)
+        tpolys = []
+        for i in range(tn):
+            pp = int(rng.integers(20, 300))
+            ang = np.sort(rng.random(pp) * 2 * np.pi)
+            rad = float(rng.integers(20, 250)) * (0.55 + 0.45 * rng.random(pp))
+            tpolys.append(np.stack([400 + rad * np.cos(ang), 300 + 0.8 * rad * np.sin(ang)], 1).astype(np.float32))
+        tb = torch.tensor([[float(c[:, 0].min()), float(c[:, 1].min()), float(c[:, 0].max()), float(c[:, 1].max())]
+                           for c in tpolys]).to(dev)
+        tcont, _ = ops.uniform_upsample(tb, v, kind=ops.POLY_BOX)
+        flat, off, _ = targets._ragged(tpolys, torch.float32, dev)
+
+        def chain():
+            dense = torch.empty((tn, v * tup, 2), dtype=torch.float64, device=dev)
+            st = torch.zeros(tn, dtype=torch.int32, device=dev)
+            check(lib().dance_dense_targets(ptr(flat), ptr(off), ptr(tcont[:, 0].contiguous()), v * tup, ptr(dense),
+                                            ptr(st), tn, current_stream()), "dense_targets")
+            re, _ext = targets.get_aux_extreme_points(dense)
+            return targets.single_uniform_multisegment_matching(re, tcont, re.ext_idx_padded, re.ext_count, tup)
+
+        chain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            _, tout, tst = chain()
+        torch.cuda.synchronize()
+        t_ms = (time.perf_counter() - t0) / 5 * 1e3
+        target_fig = {"stage": "training-side target matching (NumPy half of compute_targets_for_polys): uniform_sample("
+                               "cnt, P*%d*%d) + roll + stride -> get_aux_extreme_points -> contour roll + "
+                               "single_uniform_multisegment_matching, %d polygons of 20-300 vertices; outside the timed "
+                               "step" % (v, tup, tn),
+                      "kernel": "k_dense_targets + k_aux_extreme_points + k_multisegment_matching (one workgroup per "
+                                "instance, fp64, bit-identical to the reference's NumPy results)",
+                      "ms_wall_incl_two_syncs": t_ms, "instances_per_s": tn / (t_ms * 1e-3),
+                      "fallbacks": int((tst == 1).sum())}
+        if not args.no_cpu_baseline:
+            from oracle import targets_ref
+            k = 2
+            t0 = time.perf_counter()
+            for i in range(k):
+                c = tpolys[i]
+                big = targets_ref.uniform_sample(c, len(c) * v * tup)
+                f0 = tcont[i, 0].cpu().numpy()
+                tt = int(np.argmin(np.power(big - f0, 2).sum(axis=1)))
+                d_ = np.roll(big, -tt, axis=0)[::len(c)]
+                re_, ext_ = targets_ref.get_aux_extreme_points(d_)
+                r_ = targets_ref.roll_to_first_target(tcont[i].cpu().numpy(), re_)
+                m_, _s = targets_ref.single_uniform_multisegment_matching(re_, r_, ext_, tup, v)
+                assert np.array_equal(m_, tout[i].cpu().numpy()), "bench: target matching differs from the oracle"
+            target_fig["cpu_oracle"] = {"instances_per_s": k / (time.perf_counter() - t0), "cores": 1, "kind": "port",
+                                        "sample": "first %d of the same polygons, oracle/targets_ref.py (explicit Python "
+                                                  "loops: a checker, far slower than the reference's vectorised NumPy)" % k}
+
     if rank == 0:
         # per-stage device time from the HIP events recorded inside the timed steps
         stage_ms = [0.0] * len(STAGE_NAMES)
@@ -603,6 +665,7 @@ def main():
         rt = 2 if v <= 64 else 4 if v <= 128 else 7 if v <= 224 else 8
         # dance_res_stack16's dispatch: 8-wave kernel above 128 vertices and for few long rings
         stack_wide = v > 128 or (v > 96 and n_ev <= int(os.environ.get("DANCE_STACK_SMALL_N", "256")))
+        stack13 = 192 < v <= 208 and os.environ.get("DANCE_STACK_ODD_SPLIT", "1") != "0"   # 13 vertex tiles as 7 + 6
         if args.precision in ("fp16x3", "fp16"):
             terms = 3 if args.precision == "fp16x3" else 1
             # every algorithmic product is three f16 MFMA products (A_lo*B_hi + A_hi*B_lo +
@@ -612,7 +675,7 @@ def main():
             # that the reference's own fp32 arithmetic would be limited to
             kname = ("k_head_stack16s<%d,%d> (gather + head SnakeBlock 258->128 + the 7 residual SnakeBlocks "
                      "128->128, k=9, in one launch; %s f16 MFMA)" if head_stack else
-                     ("k_res_stack16w" if stack_wide else "k_res_stack16s") +
+                     ("k_res_stack16w13" if stack13 else "k_res_stack16w" if stack_wide else "k_res_stack16s") +
                      "<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
                      "%s f16 MFMA 16x16x32)" if stacked else
                      "k_conv16%s<%d,%d> (residual SnakeBlock 128->128, k=9, %s f16 MFMA; 7 launches "
@@ -697,13 +760,17 @@ def main():
                                                       / PEAK_HBM_GBPS},
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms,
-                             note="instrumented pass after the timed region (14 events per iteration)"),
+                             note="HIP events on the launch stream (14 boundaries per iteration).  Fast mode: "
+                                  "`fusion_max` is k_fuse16r (fusion + ring max + prediction[0]'s state part), "
+                                  "`offset_update` is k_tail16 (row constant, ReLU, prediction[2], prediction[4], "
+                                  "offset update); row_constant / pred0 / pred1 are inside those two launches"),
             "streams": args.streams,
             "two_streams": two_streams,
             "feat_prep": feat_prep,
             "mask_rle": mask_rle,
             "attender": attender_fig,
             "fcose_decode": fcose_fig,
+            "target_matching": target_fig,
             "contour_sampling": {"kernel": "k_uniform_upsample (boxes -> %d-point contours, fused resampler)" % v,
                                  "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),
                                  "note": "reference scope `contour_sampling`, outside the timed step"},
