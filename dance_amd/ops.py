@@ -61,7 +61,8 @@ def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True):
     with torch.cuda.device(poly.device):
         check(lib().dance_uniform_upsample(kind, ptr(poly), n, e, int(p_num), ptr(out), ptr(start),
                                            ptr(status), current_stream()), "uniform_upsample")
-    if check_status and n:
+    # (under HIP-graph capture the check, a host synchronisation, is skipped: dance_amd/graph.py)
+    if check_status and n and not torch.cuda.is_current_stream_capturing():
         assert not bool(status.any()), "uniform_upsample: edge counts do not sum to p_num"
     return out, start
 

@@ -1,0 +1,44 @@
+"""GPU: the one-image head as one HIP-graph replay (dance_amd/graph.py) reproduces the eager
+forward for the real detections, for changing inputs and detection counts on the same graph.
+Not to the bit: the feature-prep layers' GroupNorm statistics are fp64 ATOMIC sums (order varies
+from run to run, eager included), so the comparison allows the eager forward's own spread."""
+import pytest
+import torch
+
+from _util import edge_head_cfg
+from dance_amd import graph, modules, synthetic
+from dance_amd.structures import Boxes, Instances
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graphed_head_equals_eager(device):
+    h, w = 192, 256
+    cfg, shapes = edge_head_cfg(num_sampling=128, num_convs=2)
+    head = modules.EdgeSnakeFPNHead(cfg, shapes)
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    synthetic.fill_state_dict_(sd, 1234)
+    head.load_state_dict(sd)
+    head = head.to(device).eval()
+    g = graph.GraphedEdgeSnakeFPNHead(head, max_instances=24)
+    for seed, n in ((1, 24), (2, 7), (3, 0), (4, 19)):
+        feats = {k: synthetic.make_smooth_features(1, 256, h // s, w // s, seed + i, attention=False, cell=4).to(device)
+                 for i, (k, s) in enumerate((("p2", 4), ("p3", 8), ("p4", 16), ("p5", 32)))}
+        boxes = synthetic.make_boxes(max(n, 1), h, w, seed, r_min=6, r_max=60)[:n].to(device)
+        att_g, polys_g = g(feats, boxes, (h, w))
+        att_g, polys_g = att_g.clone(), polys_g.clone()
+        if n == 0:
+            assert polys_g.shape[0] == 0
+            continue
+        with torch.no_grad():
+            att_e, _, res = head(feats, [Instances((h, w), pred_boxes=Boxes(boxes.clone()))], None)
+            att_e2, _, res2 = head(feats, [Instances((h, w), pred_boxes=Boxes(boxes.clone()))], None)
+        want, want2 = res[0].pred_polys.tensor, res2[0].pred_polys.tensor
+        # a box clipped to zero width is a NaN contour in the reference and here (derange): same places
+        assert torch.equal(torch.isnan(polys_g), torch.isnan(want))
+        z = lambda t: torch.nan_to_num(t, nan=0.0)                      # noqa: E731
+        spread = float((z(want) - z(want2)).abs().max())
+        assert float((att_g - att_e).abs().max()) <= 1e-5
+        assert float((z(polys_g) - z(want)).abs().max()) <= max(5e-3, 4 * spread)
+        assert bool(torch.isfinite(polys_g).any())
+    assert len(g._graphs) == 1

@@ -94,3 +94,30 @@ n = len(insts[0])
 print("1 image 800x1216, %d detections -> %d contours x 128 vertices -> %d RLE masks" % (n, len(res[0].pred_polys.tensor), len(m)))
 print("predict_proposals %.2f ms | EdgeSnakeFPNHead forward %.2f ms | get_polygon_rles (incl. D2H + strings) %.2f ms | total %.2f ms"
       % (acc[0] / REPS, acc[1] / REPS, acc[2] / REPS, sum(acc) / REPS))
+
+# the same head as ONE HIP-graph replay (dance_amd/graph.py; detections padded to 100)
+from dance_amd import graph  # noqa: E402
+
+gh = graph.GraphedEdgeSnakeFPNHead(head, max_instances=100)
+boxes = insts[0].pred_boxes.tensor.clone()
+with torch.no_grad():
+    want = head(feats, [type(insts[0])((H, W), pred_boxes=type(insts[0].pred_boxes)(boxes.clone()))], None)[2][0].pred_polys.tensor
+for _ in range(3):
+    att_g, polys_g = gh(feats, boxes, (H, W))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(REPS):
+    att_g, polys_g = gh(feats, boxes, (H, W))
+torch.cuda.synchronize()
+tg = (time.perf_counter() - t0) / REPS * 1e3
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e = next(iter(gh._graphs.values()))
+ev0.record()
+for _ in range(REPS):
+    e["graph"].replay()
+ev1.record()
+torch.cuda.synchronize()
+diff = float((torch.nan_to_num(polys_g) - torch.nan_to_num(want)).abs().max())
+print("graphed head (one HIP-graph replay, detections padded to 100): %.2f ms per call incl. the 82 MB input copy, "
+      "%.2f ms per replay alone; max |contour - eager| %.2e px | total with it %.2f ms"
+      % (tg, ev0.elapsed_time(ev1) / REPS, diff, acc[0] / REPS + tg + acc[2] / REPS))
