@@ -625,11 +625,13 @@ struct Stack16Args {
 
 // The layers of the stack for one contour whose 128-channel input image already sits in LDS
 // (xs: chunk images 0 | 1) behind a barrier.
-template <int RT, int TERMS>
+// CT: 16-wide vertex tiles computed (2 * RT = the whole image width; fewer when the ring is
+// shorter: 33..48 vertices = 3 tiles in the 64-column image)
+template <int RT, int TERMS, int CT = 2 * RT>
 __device__ __forceinline__ void res_stack16_layers(const Stack16Args &a, long long nn, char *xs)
 {
     static_assert(RT <= 4, "rings of at most 128 vertices");
-    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NB = 4, CT = 2 * RT;
+    constexpr int CBC = 8, NST = CBC / 4, AD = 2, NB = (NST * CT) % 4 == 0 ? 4 : 2;
     using G = Geo<RT, CBC>;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -654,8 +656,8 @@ __device__ __forceinline__ void res_stack16_layers(const Stack16Args &a, long lo
         const int dil = a.dilation[l];
 #pragma unroll 1
         for (int c = 0; c < 2; ++c)
-            mfma16_core_s<RT, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b, wlane,
-                                                  wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, nohook);
+            mfma16_core_sw<RT, CT, NST, AD, NB, TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b, wlane,
+                                                       wps_b, wts_b, 4 * wbs_b, 9, dil, c16, q4, 0, nohook);
         __syncthreads();                    // every wave has read the whole image
         // epilogue: lane = vertex 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3; indices
         // made opaque so the compiler does not hoist the address math over the MFMAs
@@ -701,7 +703,7 @@ __device__ __forceinline__ void res_stack16_layers(const Stack16Args &a, long lo
     }
 }
 
-template <int RT, int TERMS>
+template <int RT, int TERMS, int CT = 2 * RT>
 __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
 {
     constexpr int CBC = 8, NW = 4;
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void k_res_stack16s(Stack16Args a, int n)
             }
         }
         __syncthreads();
-        res_stack16_layers<RT, TERMS>(a, nn, xs);
+        res_stack16_layers<RT, TERMS, CT>(a, nn, xs);
     }
 }
 
@@ -881,14 +883,20 @@ struct Fuse16Args {
 };
 
 // v0 / v: first vertex and vertex count of this workgroup's part of the ring (0 / a.v: whole ring)
-template <int RT, int TERMS, bool RAW>
+// NW = 8: one 8-wave workgroup per contour part and CU (all 512 outputs, 128-channel chunks).
+// NW = 4 (raw form only): the 512 outputs as two 4-wave workgroups (blockIdx.z = fusion half /
+// prediction half, 64-channel chunks, two workgroups per CU): each reads the state part itself,
+// but the two barrier domains are independent -- one's chunk barriers, prologue and tail overlap
+// the other's MFMAs.
+template <int RT, int TERMS, bool RAW, int NW = 8>
 __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, int v, int part, int parts)
 {
+    static_assert(NW == 8 || (NW == 4 && RAW), "the 4-wave split exists in the raw form only");
     // K = 1024 as one flat sequence of 64 steps of 16 channels: weights rotate through two
     // buffers over the whole sequence (no refill bubble at chunk boundaries), activations come
     // from 128-channel chunk images double-buffered in LDS, one staged load per step, ONE
     // barrier per chunk (the other image was last read two chunks ago).
-    constexpr int CBC = 16, NST = 8, NW = 8, NCH = 1024 / (CBC * 8), NT = NST * RT;
+    constexpr int CBC = 2 * NW, NST = CBC / 2, NCH = 1024 / (CBC * 8), NT = NST * RT;
     using G = Geo<RT, CBC>;
     using S = StageGeo<RT, CBC, NW>;
     constexpr int SSTEP = 2 * G::VP * 16;
@@ -896,7 +904,7 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int o0 = wave * 64;
+    const int o0 = wave * 64 + (NW == 4 ? (int)blockIdx.z * 256 : 0);
     const int vs = a.v;
     const long long wbs_b = 512 * 16, wps_b = 128 * wbs_b, wstep_b = 2 * wbs_b;
     const unsigned wlane = (unsigned)(h * 512 + r) * 16u;
@@ -904,19 +912,23 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
     const char *wbase = reinterpret_cast<const char *>(a.w) + (long long)o0 * 16;
 
     auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
-        return reinterpret_cast<const char *>(a.x + m * a.x_stride + c * a.x_slot_stride) + v0 * 16;
+        const int cb0 = c * CBC;                // first channel block of the chunk: slot cb0 / 16, block cb0 % 16
+        return reinterpret_cast<const char *>(a.x + m * a.x_stride + (cb0 >> 4) * a.x_slot_stride) +
+               (long long)(cb0 & 15) * vs * 16 + v0 * 16;
     };
 
     long long nn = blockIdx.x;
-#if DANCE_FUSE_DMA
+    // the 4-wave form stages by LDS-direct loads: it has no registers to spare for staging
+    constexpr bool DMA = DANCE_FUSE_DMA || NW == 4;
     const unsigned lds_base = __builtin_amdgcn_groupstaticsize();   // the dynamic segment follows the static one
-    stage_dma<RT, CBC, NW>(0, S::N, chunk_src(nn, 0), lds_base, v, wave, lane, vs);
-    stage_dma_wait();
-#else
-    u32x4 sreg[S::N];
-    stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane, vs);
-    stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
-#endif
+    u32x4 sreg[DMA ? 1 : S::N];
+    if constexpr (DMA) {
+        stage_dma<RT, CBC, NW>(0, S::N, chunk_src(nn, 0), lds_base, v, wave, lane, vs);
+        stage_dma_wait();
+    } else {
+        stage_load<RT, CBC, NW>(sreg, 0, S::N, chunk_src(nn, 0), v, wave, lane, vs);
+        stage_commit<RT, CBC, NW>(sreg, xs, 0, v, wave, lane);
+    }
     __syncthreads();
 
     unsigned pl[RT];                            // this lane's word in each vertex tile (no ring shift: k = 1)
@@ -960,12 +972,12 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
                     // next step's weights: the sequence runs on linearly into the next chunk
                     if (s + 1 < NST || !last)
                         F_LOAD_A((s + 1) % 2, wchunk + (s + 1) * wstep_b);
-#if DANCE_FUSE_DMA
-                    if (has_next)
-                        stage_dma<RT, CBC, NW>(s * S::N / NST, (s + 1) * S::N / NST, ssrc, lds_base + nxt, v, wave, lane, vs);
-#else
-                    stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane, vs);
-#endif
+                    if constexpr (DMA) {
+                        if (has_next)
+                            stage_dma<RT, CBC, NW>(s * S::N / NST, (s + 1) * S::N / NST, ssrc, lds_base + nxt, v, wave, lane, vs);
+                    } else {
+                        stage_load<RT, CBC, NW>(sreg, s * S::N / NST, (s + 1) * S::N / NST, ssrc, v, wave, lane, vs);
+                    }
                 }
                 if constexpr (q + 1 < NT)
                     F_LOAD_B(q + 1);
@@ -980,12 +992,12 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
                 acc[1][rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s % 2][1], bh[q % 2], acc[1][rt], 0, 0, 0);
             });
 #undef F_LOAD_B
-#if DANCE_FUSE_DMA
-            stage_dma_wait();
-#else
-            if (has_next)
-                stage_commit<RT, CBC, NW>(sreg, xs, nxt, v, wave, lane);
-#endif
+            if constexpr (DMA) {
+                stage_dma_wait();
+            } else {
+                if (has_next)
+                    stage_commit<RT, CBC, NW>(sreg, xs, nxt, v, wave, lane);
+            }
             __syncthreads();
         }
 #undef F_LOAD_A
@@ -1023,7 +1035,7 @@ __device__ __forceinline__ void fuse16_body(const Fuse16Args &a, int n, int v0, 
             }
         };
         if constexpr (RAW) {
-            if (wave < 4) {
+            if (o0 < 256) {
                 ring_max(a.gpart + (nn * parts + part) * 256);
             } else {
                 const int p0 = o0 - 256;                    // prediction output channel of tile 0
@@ -1129,6 +1141,18 @@ __global__ __launch_bounds__(512) void k_fuse16r(Fuse16Args a, int n)
         fuse16_body<RTB, TERMS, true>(a, n, v0, vn, part, parts);
     else
         fuse16_body<RTA, TERMS, true>(a, n, v0, vn, part, parts);
+}
+
+// the two-workgroup split: grid (contours, parts, 2)
+template <int RTA, int RTB, int TERMS>
+__global__ __launch_bounds__(256, 2) void k_fuse16r4(Fuse16Args a, int n)
+{
+    const int part = blockIdx.y, parts = gridDim.y;
+    const int v0 = part * a.part_v, vn = min(a.part_v, a.v - v0);
+    if (RTB != RTA && part + 1 == parts)
+        fuse16_body<RTB, TERMS, true, 4>(a, n, v0, vn, part, parts);
+    else
+        fuse16_body<RTA, TERMS, true, 4>(a, n, v0, vn, part, parts);
 }
 
 // Fused gather + de_location + head SnakeBlock, P16 flavour: chunks of 64 feature channels
@@ -1487,6 +1511,13 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
             return rc_;
         return launch_check(__func__);
     }
+    if (v > 32 && v <= 48) {                // 3 of the 64-column image's 4 vertex tiles (Dsnake's 40-point init ring)
+        if (mfma_terms == 1)
+            hipLaunchKernelGGL((k_res_stack16s<2, 1, 3>), dim3(n), dim3(256), lds, (hipStream_t)stream, a, n);
+        else
+            hipLaunchKernelGGL((k_res_stack16s<2, 3, 3>), dim3(n), dim3(256), lds, (hipStream_t)stream, a, n);
+        return launch_check(__func__);
+    }
     LAUNCH_RT24(k_res_stack16s, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
     return launch_check(__func__);
 }
@@ -1578,21 +1609,31 @@ extern "C" int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_
     const int tiles = dance::ceil_div(v, 32), parts = dance_fuse16_parts(v);
     const int rta = parts == 1 ? (tiles < 2 ? 2 : tiles) : (tiles + 1) / 2, rtb = parts == 1 ? rta : tiles - rta;
     a.part_v = parts == 1 ? v : rta * 32;
-    const size_t lds = (size_t)2 * 2 * 16 * (rta * 32 + 1) * 16;   // two 128-channel chunk images
+    // DANCE_FUSE16_WAVES=4 (read per call: the tests run both): two 4-wave workgroups per contour part
+    // (64-channel chunks, LDS-direct staging) instead of one 8-wave workgroup.  Same box, twice: fusion
+    // 0.595 / 0.600 vs 0.613 / 0.616 ms at 128 vertices, 1.055 vs 1.040 ms at 196 -- a wash, opt-in.
+    const int waves = env_int("DANCE_FUSE16_WAVES", 8);
+    const bool w4 = waves == 4;
+    const size_t lds = (size_t)2 * 2 * (w4 ? 8 : 16) * (rta * 32 + 1) * 16;   // two chunk images
     static const int slots = env_int("DANCE_FUSE16_SLOTS", 0);
-    dim3 grid(slots > 0 && slots < n ? slots : n, parts);
+    dim3 grid(slots > 0 && slots < n ? slots : n, parts, w4 ? 2 : 1);
     int rc_ = 0;
+#define FUSE_RAW_K(K, A, B, T, BLOCK)                                                              \
+    do {                                                                                           \
+        rc_ = dance::allow_lds((const void *)K<A, B, T>, lds, "dance_fuse16_raw");                 \
+        if (!rc_)                                                                                  \
+            hipLaunchKernelGGL((K<A, B, T>), grid, dim3(BLOCK), lds, (hipStream_t)stream, a, n);   \
+    } while (0)
 #define FUSE_RAW(A, B)                                                                             \
     do {                                                                                           \
-        if (mfma_terms == 1) {                                                                     \
-            rc_ = dance::allow_lds((const void *)k_fuse16r<A, B, 1>, lds, "dance_fuse16_raw");     \
-            if (!rc_)                                                                              \
-                hipLaunchKernelGGL((k_fuse16r<A, B, 1>), grid, dim3(512), lds, (hipStream_t)stream, a, n); \
-        } else {                                                                                   \
-            rc_ = dance::allow_lds((const void *)k_fuse16r<A, B, 3>, lds, "dance_fuse16_raw");     \
-            if (!rc_)                                                                              \
-                hipLaunchKernelGGL((k_fuse16r<A, B, 3>), grid, dim3(512), lds, (hipStream_t)stream, a, n); \
-        }                                                                                          \
+        if (w4 && mfma_terms == 1)                                                                 \
+            FUSE_RAW_K(k_fuse16r4, A, B, 1, 256);                                                  \
+        else if (w4)                                                                               \
+            FUSE_RAW_K(k_fuse16r4, A, B, 3, 256);                                                  \
+        else if (mfma_terms == 1)                                                                  \
+            FUSE_RAW_K(k_fuse16r, A, B, 1, 512);                                                   \
+        else                                                                                       \
+            FUSE_RAW_K(k_fuse16r, A, B, 3, 512);                                                   \
     } while (0)
     if (rta == 2 && rtb == 2)
         FUSE_RAW(2, 2);
@@ -1607,6 +1648,7 @@ extern "C" int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_
     else
         return dance::fail((int)hipErrorInvalidValue, __func__, "unsupported split of the ring");
 #undef FUSE_RAW
+#undef FUSE_RAW_K
     if (rc_)
         return rc_;
     return launch_check(__func__);

@@ -145,3 +145,19 @@ def test_fuse_raw_tail_reruns_are_bit_identical_with_late_workgroups(device, v):
     _, alone = _fused(net.struct16, state[-k:].contiguous(), loc[-k:].contiguous(), whs[-k:].contiguous(),
                       att[-k:].contiguous(), k, v, 3, False)
     assert torch.equal(outs[0][-k:], alone)
+
+
+@pytest.mark.parametrize("v", [40, 128, 196, 256])
+def test_fuse_raw_four_wave_split_equals_eight_wave(device, v, monkeypatch):
+    """DANCE_FUSE16_WAVES=4: the 512 outputs as two 4-wave workgroups (64-channel chunks staged by
+    LDS-direct loads).  Same products in the same order per output element: identical bits."""
+    cfg, sd, _ = dance_state_dict(35, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer2."), device)
+    n = 300
+    x, state, loc, whs, att = _inputs(n, v, device, 11)
+    res = {}
+    for waves in ("8", "4"):
+        monkeypatch.setenv("DANCE_FUSE16_WAVES", waves)
+        res[waves] = [_fused(net.struct16, state, loc, whs, att, n, v, terms, False) for terms in (3, 1)]
+    for a, b in zip(res["8"], res["4"]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
