@@ -52,6 +52,12 @@ class SnakeNet16Struct(ctypes.Structure):
     ]
 
 
+class InitFuse16Struct(ctypes.Structure):
+    """Mirror of `dance_init_fuse16` (include/dance_hip.h)."""
+
+    _fields_ = [("w16", c_void_p), ("wg_center", c_void_p), ("bias", c_void_p), ("w_inv_scale", c_float)]
+
+
 class FcoseLevelStruct(ctypes.Structure):
     """Mirror of `dance_fcose_level` (include/dance_hip.h)."""
 
@@ -122,6 +128,11 @@ SIGNATURES = {
     "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int, P]),
     "dance_head_stack16": (c_int, [POINTER(SnakeNet16Struct), P, P, P, P, P, c_int64, c_int64, P, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_init_head16": (c_int, [P, P, P, P, c_float, P, P, P, P, c_float, P, P, P, c_int64, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_snake_init16": (c_int, [POINTER(SnakeNet16Struct), POINTER(InitFuse16Struct), P, P, P, P, P,
+                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   POINTER(c_void_p), P]),
     "dance_snake_evolve16": (c_int, [POINTER(SnakeNet16Struct), POINTER(SnakeNetStruct), P, P, P, P, P,
                                      P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_float, c_float, c_int, POINTER(c_void_p), P]),

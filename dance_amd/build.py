@@ -26,6 +26,7 @@ SOURCES = [
     ("snake_mfma.hip", []),
     ("snake16.hip", []),
     ("tail16.hip", []),
+    ("init16.hip", []),
     ("featprep16.hip", []),
     ("raster.hip", ["-ffp-contract=off"]),
     ("attender.hip", []),

@@ -141,4 +141,17 @@ __device__ __forceinline__ void init_acc16(f32x16 (&acc)[OTW][RT], const float *
 
 __device__ __forceinline__ float relu_nan(float x) { return x > 0.0f ? x : (x != x ? x : 0.0f); }
 
+// acc = fma(a, b, acc) as ONE v_fmac_f32 the compiler cannot pair into v_pk_fma_f32.
+// Measured on MI355X (round 2, tools/tail_probe.py): with the row-constant GEMV of k_tail16 compiled to
+// v_pk_fma_f32 (accumulator pairs, the LDS-sourced factor broadcast through op_sel, younger
+// global loads of the same wave still in flight), workgroups that start while other workgroups
+// of the CU are in their MFMA phase get wrong LOW halves of the pairs in lanes 48..63 -- run to
+// run different, ~1e-2 relative, every counter wait in the ISA in place.  The first resident
+// batch of workgroups (all in the GEMV at the same time, no MFMA beside it) never shows it, nor
+// does the same code with single v_fmac_f32.  Cause not established; the GEMV stays unpaired.
+__device__ __forceinline__ void fma1(float &acc, float a, float b)
+{
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 }  // namespace

@@ -622,73 +622,37 @@ extern "C" int dance_snake_evolve(const dance_snake_net *net, const float *feat,
     return 0;
 }
 
+namespace {
 
-// ------------------------------------------------------------------------------------
-// One evolve step in the fast precision mode (P16 activations, 3 x f16 MFMA): same stages,
-// fusion + row constant + prediction[0] fused into one kernel that reads the state once.
-// ------------------------------------------------------------------------------------
-extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_snake_net *net32,
-                                    const float *feat, const float *att, const float *loc,
-                                    const int32_t *image_idx, const float *whs, const float *x_in,
-                                    float *out, void *workspace, int64_t workspace_bytes, int n, int v,
-                                    int b, int hf, int wf, int padding_mode, int deloc_type,
-                                    int individual_scale, int use_att, int clip_first,
-                                    float clip_x_max, float clip_y_max, int mfma_terms,
-                                    void **stage_events_host, void *stream)
-{
-    DANCE_REQUIRE(net != nullptr && n >= 0);
-    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
-    if (n == 0)
-        return 0;
-    DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr);
-    DANCE_REQUIRE(v >= 16 && v <= 256 && v % 4 == 0);
-    const int c = net->feat_channels;
-    DANCE_REQUIRE(c >= 64 && c % 64 == 0 && c + 2 <= 272);
-    DANCE_REQUIRE(!individual_scale || whs != nullptr);
-    DANCE_REQUIRE(!use_att || att != nullptr);
-    DANCE_REQUIRE(x_in != nullptr || feat != nullptr);
-    (void)net32;
-    Workspace w = carve(workspace, n, v, 272);
-    DANCE_REQUIRE(workspace_bytes >= w.bytes);
-    _Float16 *state = reinterpret_cast<_Float16 *>(w.state);     // (n, 8 slots) P16
-    _Float16 *p1 = reinterpret_cast<_Float16 *>(w.p1);           // (n, 2 slots) P16
-    const long long slot = 256ll * v, sstride = 8 * slot, pstride = 2 * slot;
+// stage-boundary events of one evolve call (bench instrumentation; null: nothing recorded)
+struct StageMarks {
+    void **events;
+    void *stream;
+    const char *fn;
     int stage = 0;
-    auto mark = [&]() -> int {
-        if (stage_events_host == nullptr)
+    int operator()()
+    {
+        if (events == nullptr)
             return 0;
-        void *ev = stage_events_host[stage++];
+        void *ev = events[stage++];
         if (ev == nullptr)                       // sparse instrumentation: this boundary is not timed
             return 0;
         hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
-        return e == hipSuccess ? 0 : dance::fail((int)e, "dance_snake_evolve16", hipGetErrorString(e));
-    };
-    DANCE_TRY(mark());
-    if (x_in != nullptr) {
-        // precomputed fp32 input (Dsnake init): the head block of the fast mode, input split
-        // into hi/lo halves while it is staged
-        DANCE_TRY(dance_xin_head16(x_in, (long long)(c + 2) * v, net->head_w, net->head_bs, net->head_winv,
-                                   net->head_scale, net->head_shift, state, sstride, n, v, c, mfma_terms,
-                                   stream));
+        return e == hipSuccess ? 0 : dance::fail((int)e, fn, hipGetErrorString(e));
     }
+};
+
+// The fast mode after the head block (state slot 0 written): residual stack, fusion, tail.
+int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, bool head_stack, const float *loc,
+                        const float *whs, const float *att_s, float *out, int n, int v, int clip_first,
+                        float clip_x_max, float clip_y_max, int mfma_terms, StageMarks &mark, void *stream)
+{
+    _Float16 *state = reinterpret_cast<_Float16 *>(w.state);     // (n, 8 slots) P16
+    _Float16 *p1 = reinterpret_cast<_Float16 *>(w.p1);           // (n, 2 slots) P16
+    const long long slot = 256ll * v, sstride = 8 * slot, pstride = 2 * slot;
     static const int use_stack = getenv("DANCE_RES_STACK") ? atoi(getenv("DANCE_RES_STACK")) : 1;
-    // opt-in (DANCE_HEAD_STACK=1): measured no faster than the two launches (DESIGN.md, experiments)
-    static const int use_head_stack = getenv("DANCE_HEAD_STACK") ? atoi(getenv("DANCE_HEAD_STACK")) : 0;
     // rings above 128 vertices: the 8-wave stack kernel (DANCE_RES_STACK_WIDE=0: one launch per block)
     static const int use_stack_wide = getenv("DANCE_RES_STACK_WIDE") ? atoi(getenv("DANCE_RES_STACK_WIDE")) : 1;
-    const bool head_stack = x_in == nullptr && use_stack && use_head_stack && v <= 128;
-    if (head_stack) {
-        // gather + head block + the 7 residual blocks in one launch; its time is booked on stage head
-        DANCE_TRY(dance_head_stack16(net, feat, att, loc, image_idx, state, sstride, slot,
-                                     use_att ? w.att_s : nullptr, n, v, b, hf, wf, padding_mode, deloc_type,
-                                     mfma_terms, stream));
-    } else if (x_in == nullptr) {
-        DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
-                                      net->head_winv, net->head_scale, net->head_shift, state, sstride,
-                                      use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
-                                      deloc_type, mfma_terms, stream));
-    }
-    DANCE_TRY(mark());
     if (head_stack) {
         for (int i = 0; i < 7; ++i)
             DANCE_TRY(mark());
@@ -721,7 +685,7 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
         DANCE_TRY(mark());      // prediction[2]: the tail kernel, booked on the last stage
         DANCE_TRY(dance_tail16(p1, pstride, slot, gpart, parts, net->pred0_wg, net->pred0_b, net->pred1_w,
                                net->pred1_bs, net->pred1_winv, net->pred2_w, net->pred2_b, loc,
-                               individual_scale ? whs : nullptr, use_att ? w.att_s : nullptr, out, n, v,
+                               whs, att_s, out, n, v,
                                clip_first, clip_x_max, clip_y_max, mfma_terms, stream));
         DANCE_TRY(mark());
         return 0;
@@ -752,8 +716,101 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
                            1, mfma_terms, stream));
     DANCE_TRY(mark());
     DANCE_TRY(dance_offset_update(w.p2, 64ll * v, net->pred2_w, net->pred2_b, loc,
-                                  individual_scale ? whs : nullptr, use_att ? w.att_s : nullptr, out,
+                                  whs, att_s, out,
                                   n, v, 64, clip_first, clip_x_max, clip_y_max, stream));
     DANCE_TRY(mark());
     return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// One evolve step in the fast precision mode (P16 activations, 3 x f16 MFMA): same stages,
+// fusion + row constant + prediction[0] fused into one kernel that reads the state once.
+// ------------------------------------------------------------------------------------
+extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_snake_net *net32,
+                                    const float *feat, const float *att, const float *loc,
+                                    const int32_t *image_idx, const float *whs, const float *x_in,
+                                    float *out, void *workspace, int64_t workspace_bytes, int n, int v,
+                                    int b, int hf, int wf, int padding_mode, int deloc_type,
+                                    int individual_scale, int use_att, int clip_first,
+                                    float clip_x_max, float clip_y_max, int mfma_terms,
+                                    void **stage_events_host, void *stream)
+{
+    DANCE_REQUIRE(net != nullptr && n >= 0);
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr);
+    DANCE_REQUIRE(v >= 16 && v <= 256 && v % 4 == 0);
+    const int c = net->feat_channels;
+    DANCE_REQUIRE(c >= 64 && c % 64 == 0 && c + 2 <= 272);
+    DANCE_REQUIRE(!individual_scale || whs != nullptr);
+    DANCE_REQUIRE(!use_att || att != nullptr);
+    DANCE_REQUIRE(x_in != nullptr || feat != nullptr);
+    (void)net32;
+    Workspace w = carve(workspace, n, v, 272);
+    DANCE_REQUIRE(workspace_bytes >= w.bytes);
+    _Float16 *state = reinterpret_cast<_Float16 *>(w.state);     // (n, 8 slots) P16
+    const long long slot = 256ll * v, sstride = 8 * slot;
+    StageMarks mark{stage_events_host, stream, "dance_snake_evolve16"};
+    DANCE_TRY(mark());
+    if (x_in != nullptr) {
+        // precomputed fp32 input (Dsnake init): the head block of the fast mode, input split
+        // into hi/lo halves while it is staged
+        DANCE_TRY(dance_xin_head16(x_in, (long long)(c + 2) * v, net->head_w, net->head_bs, net->head_winv,
+                                   net->head_scale, net->head_shift, state, sstride, n, v, c, mfma_terms,
+                                   stream));
+    }
+    static const int use_stack = getenv("DANCE_RES_STACK") ? atoi(getenv("DANCE_RES_STACK")) : 1;
+    // opt-in (DANCE_HEAD_STACK=1): measured no faster than the two launches (DESIGN.md, experiments)
+    static const int use_head_stack = getenv("DANCE_HEAD_STACK") ? atoi(getenv("DANCE_HEAD_STACK")) : 0;
+    const bool head_stack = x_in == nullptr && use_stack && use_head_stack && v <= 128;
+    if (head_stack) {
+        // gather + head block + the 7 residual blocks in one launch; its time is booked on stage head
+        DANCE_TRY(dance_head_stack16(net, feat, att, loc, image_idx, state, sstride, slot,
+                                     use_att ? w.att_s : nullptr, n, v, b, hf, wf, padding_mode, deloc_type,
+                                     mfma_terms, stream));
+    } else if (x_in == nullptr) {
+        DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
+                                      net->head_winv, net->head_scale, net->head_shift, state, sstride,
+                                      use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
+                                      deloc_type, mfma_terms, stream));
+    }
+    DANCE_TRY(mark());
+    return evolve16_after_head(net, w, head_stack, loc, individual_scale ? whs : nullptr,
+                               use_att ? w.att_s : nullptr, out, n, v, clip_first, clip_x_max, clip_y_max,
+                               mfma_terms, mark, stream);
+}
+
+// ------------------------------------------------------------------------------------
+// Dsnake's init stage in the fast precision mode (DsnakeHead.init, dsnake_head.py:718-744):
+// gather + centre feature + fuse Conv1d + de_location + the init snake's head block in one
+// launch (init16.hip), then the same residual stack / fusion / tail as an evolve step.
+// No attention, no individual scale, no clipping (the caller clamps the extreme points).
+// ------------------------------------------------------------------------------------
+extern "C" int dance_snake_init16(const dance_snake_net16 *net, const dance_init_fuse16 *fuse,
+                                  const float *feat, const float *loc, const int32_t *image_idx, float *out,
+                                  void *workspace, int64_t workspace_bytes, int n, int v, int b, int hf,
+                                  int wf, int padding_mode, int deloc_type, int mfma_terms,
+                                  void **stage_events_host, void *stream)
+{
+    DANCE_REQUIRE(net != nullptr && fuse != nullptr && n >= 0);
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr && feat != nullptr);
+    DANCE_REQUIRE(v >= 16 && v <= 64 && v % 4 == 0);
+    DANCE_REQUIRE(net->feat_channels == 256);
+    Workspace w = carve(workspace, n, v, 272);
+    DANCE_REQUIRE(workspace_bytes >= w.bytes);
+    StageMarks mark{stage_events_host, stream, "dance_snake_init16"};
+    DANCE_TRY(mark());
+    DANCE_TRY(dance_init_head16(feat, loc, image_idx, fuse->w16, fuse->w_inv_scale, fuse->wg_center, fuse->bias,
+                                net->head_w, net->head_bs, net->head_winv, net->head_scale, net->head_shift,
+                                w.state, 2048ll * v, n, v, b, hf, wf, 256, padding_mode, deloc_type, mfma_terms,
+                                stream));
+    DANCE_TRY(mark());
+    return evolve16_after_head(net, w, false, loc, nullptr, nullptr, out, n, v, 0, 0.0f, 0.0f, mfma_terms,
+                               mark, stream);
 }

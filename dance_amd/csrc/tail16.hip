@@ -38,19 +38,6 @@ struct Tail16Args {
     float clip_x, clip_y;
 };
 
-// acc = fma(a, b, acc) as ONE v_fmac_f32 the compiler cannot pair into v_pk_fma_f32.
-// Measured on MI355X (round 2, tools/tail_probe.py): with the row-constant GEMV below compiled to
-// v_pk_fma_f32 (accumulator pairs, the LDS-sourced factor broadcast through op_sel, younger
-// global loads of the same wave still in flight), workgroups that start while other workgroups
-// of the CU are in their MFMA phase get wrong LOW halves of the pairs in lanes 48..63 -- run to
-// run different, ~1e-2 relative, every counter wait in the ISA in place.  The first resident
-// batch of workgroups (all in the GEMV at the same time, no MFMA beside it) never shows it, nor
-// does the same code with single v_fmac_f32.  Cause not established; the GEMV stays unpaired.
-__device__ __forceinline__ void fma1(float &acc, float a, float b)
-{
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
-}
-
 template <int RT, int TERMS, int GC>
 __global__ __launch_bounds__(256, 2) void k_tail16(Tail16Args a, int n)
 {

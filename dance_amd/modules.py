@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops, timer
+from ._lib import InitFuse16Struct
 from .config import SnakeHeadConfig
 from .snake import ContourDeformer, SnakeNetWeights, sub_state_dict
 from .structures import ExtremePoints, PolygonPoints
@@ -402,12 +403,30 @@ class DsnakeHead(_SnakeHeadBase):
             self._fuse_w_sampled = ops.pack_conv_weight(w[:, :c, :])
             self._fuse_wg_center = w[:, c:, 0].t().contiguous()       # [g][o]
             self._fuse_b = self.fuse.bias.detach().float().contiguous()
+            # the same Conv1d for the one-launch init stage of the fast precision mode (init16.hip)
+            self._fuse_w16, sc = ops.pack_conv_weight16(w[:, :c, :])
+            f = InitFuse16Struct()
+            f.w16, f.wg_center, f.bias = (self._fuse_w16.data_ptr(), self._fuse_wg_center.data_ptr(),
+                                          self._fuse_b.data_ptr())
+            f.w_inv_scale = 1.0 / sc
+            self._fuse16 = f
         return self._deformer
 
     def init_stage(self, d, feat, init_locations, idx):
         """DsnakeHead.init (dsnake_head.py:718-746): 40-point quadrangle + centre feature
         -> fuse Conv1d -> init snake -> 4 extreme points."""
+        return self.init_contours(d, feat, init_locations, idx)[:, ::10]
+
+    def init_contours(self, d, feat, init_locations, idx, one_launch=None):
+        """The init snake's deformed ring (dsnake_head.py:718-744).  one_launch (default: whenever
+        the deformer supports it, DANCE_INIT16=0 to switch off): gather + centre feature + fuse +
+        de_location + head block as one kernel of the fast precision mode (csrc/init16.hip);
+        otherwise separate launches with `fuse` as an exact fp32 convolution."""
         c = feat.shape[-1]
+        if one_launch is None:
+            one_launch = os.environ.get("DANCE_INIT16", "1") != "0"
+        if one_launch and d.supports_init_evolve(c, init_locations.shape[1]):
+            return d.init_evolve(0, feat, init_locations, idx, self._fuse16)
         sampled, _ = ops.gather_features(feat, None, init_locations, idx, ops.PAD_ZEROS, "demin")
         center = (torch.min(init_locations, dim=1)[0] + torch.max(init_locations, dim=1)[0]) * 0.5
         cfeat, _ = ops.gather_features(feat, None, center[:, None].contiguous(), idx, ops.PAD_ZEROS, None)
@@ -418,9 +437,8 @@ class DsnakeHead(_SnakeHeadBase):
         ops.circconv(sampled, self._fuse_w_sampled, None, cin=c, rowinit=rowinit,
                      out=x[:, :c])
         x[:, c:] = sampled[:, c:]
-        pred = d.evolve(0, feat, None, init_locations, idx, None, use_att=False, clip_first=False,
+        return d.evolve(0, feat, None, init_locations, idx, None, use_att=False, clip_first=False,
                         clip_max=(0.0, 0.0), x_in=x)
-        return pred[:, ::10]
 
     def forward(self, features, pred_instances=None, targets=None):
         """dsnake_head.py:767-855, inference branch."""

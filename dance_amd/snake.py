@@ -253,6 +253,46 @@ class ContourDeformer:
                     ev, stream), "snake_evolve")
         return out
 
+    def init_evolve(self, it, feat, locations, image_idx, fuse, out=None, stage_events=None):
+        """Dsnake's init stage (DsnakeHead.init, dsnake_head.py:718-744) with deformer `it` in one
+        kernel sequence of the fast precision mode: gather + centre feature + `fuse` +
+        de_location + head block in one launch, then stack / fusion / tail.  fuse: InitFuse16Struct
+        (the packed `fuse` Conv1d).  Needs 256 feature channels and rings of at most 64 vertices
+        (`supports_init_evolve`)."""
+        net = self.nets[it]
+        n, v, _ = locations.shape
+        dev = locations.device
+        locations = locations.contiguous()
+        if out is None:
+            out = torch.empty((n, v, 2), dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        b, hf, wf, c = feat.shape
+        if not self.supports_init_evolve(c, v):
+            raise RuntimeError("init_evolve needs the fast precision mode, 256 channels, 16 <= v <= 64")
+        if image_idx is not None and image_idx.dtype != torch.int32:
+            image_idx = image_idx.to(torch.int32)
+        chunk = min(n, self.MAX_CHUNK)
+        ws, need = self._workspace(chunk, v, dev)
+        ev = None
+        if stage_events is not None:
+            if n > chunk or len(stage_events) != EVOLVE_EVENTS:
+                raise RuntimeError("stage events need a single-chunk call and %d events" % EVOLVE_EVENTS)
+            ev = (ctypes.c_void_p * EVOLVE_EVENTS)(*[None if e is None else e.cuda_event for e in stage_events])
+        with torch.cuda.device(dev):
+            stream = current_stream()
+            for n0 in range(0, n, chunk):
+                nb = min(chunk, n - n0)
+                check(lib().dance_snake_init16(
+                    ctypes.byref(net.struct16), ctypes.byref(fuse), ptr(feat), ptr(locations[n0:]),
+                    ptr(image_idx[n0:]) if image_idx is not None else None, ptr(out[n0:]), ptr(ws), need,
+                    nb, v, b, hf, wf, self.padding, self.deloc, 1 if self.precision == "fp16" else 3,
+                    ev, stream), "snake_init16")
+        return out
+
+    def supports_init_evolve(self, c, v):
+        return self.precision in ("fp16x3", "fp16") and c == 256 and 16 <= v <= 64 and v % 4 == 0
+
     def deform(self, features, init_contours, image_idx, image_sizes, whs, layout="nchw",
                stage_events=None, streams=1):
         """features: NCHW (B,[1+]C,Hf,Wf) as the reference's evolve loop sees it after

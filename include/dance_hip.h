@@ -464,6 +464,28 @@ int dance_xin_head16(const float *x_in, int64_t x_stride, const void *w16, const
                      float w_inv_scale, const float *scale, const float *shift, void *y16,
                      int64_t y_stride, int n, int v, int c, int mfma_terms, void *stream);
 
+/* Dsnake's init stage up to the init snake's head block in one launch (c = 256, 16 <= v <= 64):
+ * bilinear gather at the ring's vertices and at its centre (min + max) / 2, fuse Conv1d(2c -> c,
+ * k = 1) with the centre half folded into a per-contour row constant (fuse_w16: the sampled half
+ * packed (2,1,32,256,8) with inverse scale fuse_w_inv_scale; fuse_wg: the centre half as [g][o]
+ * (256,256) fp32; fuse_bias (256)), de_location, head SnakeBlock -> slot 0 of a P16 block.
+ * reference: DsnakeHead.init dsnake_head.py:718-736 (+ get_locations_feature :678-695,
+ * de_location :697-708, _SnakeNet.head :99, :120). */
+int dance_init_head16(const float *feat, const float *loc, const int32_t *image_idx,
+                      const void *fuse_w16, float fuse_w_inv_scale, const float *fuse_wg,
+                      const float *fuse_bias, const void *head_w16, const float *head_bias_scaled,
+                      float head_w_inv_scale, const float *head_scale, const float *head_shift,
+                      void *y16, int64_t y_stride, int n, int v, int b, int hf, int wf, int c,
+                      int padding_mode, int deloc_type, int mfma_terms, void *stream);
+
+/* DsnakeHead.fuse (dsnake_head.py:242, Conv1d(2c, c, 1)) packed for dance_init_head16. */
+typedef struct dance_init_fuse16 {
+    const void *w16;            /* sampled half, split-half packing (2,1,c/8,c,8) */
+    const float *wg_center;     /* centre half, [g][o] (c, c) */
+    const float *bias;          /* (c) */
+    float w_inv_scale;
+} dance_init_fuse16;
+
 typedef struct dance_snake_net16 {
     const void *head_w;  const float *head_bs, *head_scale, *head_shift;
     const void *res_w[7]; const float *res_bs[7], *res_scale[7], *res_shift[7];
@@ -503,6 +525,16 @@ int dance_snake_evolve16(const dance_snake_net16 *net_host, const dance_snake_ne
                          int wf, int padding_mode, int deloc_type, int individual_scale, int use_att,
                          int clip_first, float clip_x_max, float clip_y_max, int mfma_terms,
                          void **stage_events_host, void *stream);
+
+/* Dsnake's whole init stage in the fast precision mode: dance_init_head16 with the init snake's
+ * head block, then the residual stack, fusion and tail of dance_snake_evolve16 (no attention, no
+ * individual scale, no clipping): out = loc + offsets, (n, v, 2).  Same workspace and stage
+ * events as dance_snake_evolve16.  reference: DsnakeHead.init dsnake_head.py:718-744. */
+int dance_snake_init16(const dance_snake_net16 *net_host, const dance_init_fuse16 *fuse_host,
+                       const float *feat, const float *loc, const int32_t *image_idx, float *out,
+                       void *workspace, int64_t workspace_bytes, int n, int v, int b, int hf, int wf,
+                       int padding_mode, int deloc_type, int mfma_terms, void **stage_events_host,
+                       void *stream);
 
 #ifdef __cplusplus
 }
