@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -49,6 +49,7 @@ class SnakeNet16Struct(ctypes.Structure):
         ("pred1_winv", c_float),
         ("dilation", c_int * 7),
         ("feat_channels", c_int),
+        ("head_wd", c_void_p),
     ]
 
 
@@ -124,6 +125,8 @@ SIGNATURES = {
                              c_int, c_int, c_float, c_float, c_int, P]),
     "dance_gather_head16": (c_int, [P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_gather_head16w": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_xin_head16": (c_int, [P, c_int64, P, P, c_float, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int, P]),
     "dance_head_stack16": (c_int, [POINTER(SnakeNet16Struct), P, P, P, P, P, c_int64, c_int64, P, c_int, c_int,

@@ -8,6 +8,7 @@ library is a plain C ABI (include/dance_hip.h).
 """
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -27,6 +28,7 @@ SOURCES = [
     ("snake16.hip", []),
     ("tail16.hip", []),
     ("init16.hip", []),
+    ("head16.hip", []),
     ("featprep16.hip", []),
     ("raster.hip", ["-ffp-contract=off"]),
     ("attender.hip", []),
@@ -47,7 +49,7 @@ def build(force=False, keep_asm=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    objs = []
+    objs, cmds = [], []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
@@ -58,7 +60,11 @@ def build(force=False, keep_asm=False, verbose=False):
                 cmd += ["-save-temps=obj"]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd, cwd=OBJ)
+            cmds.append(cmd)
+    # translation units are independent: compile them side by side (DANCE_BUILD_JOBS, default 6)
+    jobs = max(1, int(os.environ.get("DANCE_BUILD_JOBS", "6")))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(lambda c: subprocess.check_call(c, cwd=OBJ), cmds))
     if force or _newer(OUT, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:

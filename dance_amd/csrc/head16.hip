@@ -1,0 +1,267 @@
+// head16.hip -- fused gather + de_location + head SnakeBlock of the fast precision mode on
+// v_mfma_f32_16x16x32_f16 with 16-wide vertex tiles (RefineNet.evolve snake_head.py:1639-1652,
+// get_locations_feature :1542-1572, de_location :1587-1610, _SnakeNet.head :233).
+//
+// Same work as k_gather_head16 (snake16.hip: 32 x 32 x 16 tiles, the ring padded to a multiple of
+// 32 columns) with two differences:
+//   * a wave's 32 outputs x the whole ring are 2 row tiles x CT column tiles of 16, CT =
+//     ceil(v / 16) rounded up to an instantiated count: 196 vertices run 13 tiles (208 columns)
+//     instead of 224, 40 vertices 3 (48) instead of 64;
+//   * the two de_location channels do not ride a zero-padded 32-channel chunk through all 9 ring
+//     taps; their 2 x 9 (channel, tap) pairs are laid out as ONE 32-deep K step (an im2col column
+//     per vertex: dx at the 9 ring offsets, dy at the 9 ring offsets, 14 zeros) against the
+//     matching 128 x 32 slice of the head weights (`head_wd`, packed with the head's scale).
+// Results differ from k_gather_head16's only in summation order (~1e-7 relative).
+#include "common.h"
+#include "mfma16.h"
+#include "p16.h"
+#include "sampling.h"
+
+using dance::launch_check;
+
+namespace {
+
+struct Head16Args {
+    const float *feat, *att, *loc;
+    const int *image_idx;
+    float *att_out;
+    int b, hf, wf, c, reflection, deloc;
+    const h8 *w;                // head weights [plane][9][cin/8][128] words (feature blocks used)
+    int cin;                    // padded input channels of w
+    const h8 *wd;               // de_location im2col weights [plane][4][128] words
+    const float *bias_s, *scale, *shift;
+    float winv;
+    _Float16 *y;                // state slot 0 (P16)
+    long long y_stride;
+    int v;
+};
+
+template <int RTG, int CT, int TERMS>
+__global__ __launch_bounds__(256, 2) void k_gather_head16w(Head16Args a)
+{
+    constexpr int NST = 2, AD = 2, NB = (NST * CT) % 4 == 0 && CT >= 3 ? 4 : 2;
+    static_assert(CT * 16 <= RTG * 32, "the column tiles fit the image");
+    using G = Geo<RTG, 8>;
+    using GD = Geo<RTG, 4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int v = a.v;
+    char *xs = smem;                                            // one chunk image
+    float *tw = reinterpret_cast<float *>(smem + G::BYTES);     // [v][4]
+    int *toff = reinterpret_cast<int *>(tw + 4 * v);            // [v][4]
+    float *dl = reinterpret_cast<float *>(toff + 4 * v);        // [2][v]
+    float *red = dl + 2 * v;                                    // [16]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const long long nn = blockIdx.x;
+    const int o0 = wave * 32;
+    const float *loc_n = a.loc + nn * v * 2;
+    int img = a.image_idx ? a.image_idx[nn] : a.b - 1;
+    const bool img_ok = img >= 0 && img < a.b;
+    img = img_ok ? img : 0;
+    const long long plane = (long long)a.hf * a.wf;
+
+    float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
+    if (a.deloc != DANCE_DELOC_NONE)
+        dance::contour_bounds(loc_n, v, red, xmin, xmax, ymin, ymax);
+    for (int vi = t; vi < v; vi += 256) {
+        const float lx = loc_n[2 * vi], ly = loc_n[2 * vi + 1];
+        dance::Taps tp = dance::bilinear_taps(lx, ly, a.hf, a.wf, a.reflection);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tw[vi * 4 + k] = img_ok ? tp.w[k] : 0.0f;
+            toff[vi * 4 + k] = tp.off[k];
+        }
+        if (a.att_out != nullptr) {
+            float s = 0.0f;
+            if (a.att != nullptr) {
+#pragma clang fp contract(off)
+                const float *ap = a.att + img * plane;
+                s = ap[tp.off[0]] * tp.w[0] + ap[tp.off[1]] * tp.w[1] + ap[tp.off[2]] * tp.w[2] +
+                    ap[tp.off[3]] * tp.w[3];
+                s = img_ok ? s : 0.0f;
+            }
+            a.att_out[nn * v + vi] = s;
+        }
+        if (a.deloc != DANCE_DELOC_NONE) {
+            dl[vi] = dance::deloc_value(lx, xmin, xmax, a.deloc);
+            dl[v + vi] = dance::deloc_value(ly, ymin, ymax, a.deloc);
+        }
+    }
+
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s + o0 + 16 * i + 4 * q4);
+        const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+            acc[i][j] = bv;
+    }
+
+    if (a.deloc != DANCE_DELOC_NONE) {
+        // de_location as one K step: word (block kb, vertex vi) = im2col entries 8 kb .. 8 kb + 7 of
+        // [dx(vi - 4 .. vi + 4), dy(vi - 4 .. vi + 4), 0 x 14]
+        __syncthreads();
+        for (int i = t; i < 4 * v; i += 256) {
+            const int kb = i / v, vi = i - kb * v;
+            h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb * 8 + e;
+                if (k < 18) {
+                    const int ch = k >= 9, tap = k - 9 * ch;
+                    _Float16 p, q;
+                    dance::split_half(dl[ch * v + ring16(vi, tap - 4, v)], p, q);
+                    hi[e] = p;
+                    lo[e] = q;
+                }
+            }
+            *reinterpret_cast<h8 *>(xs + (kb * GD::VP + vi) * 16) = hi;
+            *reinterpret_cast<h8 *>(xs + GD::PLANE + (kb * GD::VP + vi) * 16) = lo;
+        }
+        __syncthreads();
+        h8 ah[2], al[2];
+        const char *wdp = reinterpret_cast<const char *>(a.wd) + (unsigned)(q4 * 128 + o0 + c16) * 16u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const h8 *>(wdp + i * 256);
+            if constexpr (TERMS == 3)
+                al[i] = *reinterpret_cast<const h8 *>(wdp + 4 * 128 * 16 + i * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const char *bq = xs + (unsigned)(q4 * GD::VP + min(j * 16 + c16, v - 1)) * 16u;
+            const h8 bh = *reinterpret_cast<const h8 *>(bq);
+            if constexpr (TERMS == 3) {
+                const h8 bl = *reinterpret_cast<const h8 *>(bq + GD::PLANE);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], bh, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bl, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bl, acc[1][j], 0, 0, 0);
+            }
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bh, acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bh, acc[1][j], 0, 0, 0);
+        }
+    }
+
+    const long long wbs_b = 128ll * 16, wts_b = (long long)(a.cin >> 3) * wbs_b, wps_b = 9 * wts_b;
+    const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
+    const float *fimg = a.feat + img * plane * a.c;
+    const int lc = t & 15, vs = t >> 4;                         // 16 lanes x float4 = 64 channels
+    auto nohook = [](int) __attribute__((always_inline)) {};
+    for (int c0 = 0; c0 < a.c; c0 += 64) {
+        __syncthreads();
+#pragma unroll 2
+        for (int s = vs; s < v; s += 16) {
+#pragma clang fp contract(off)
+            const float w0 = tw[s * 4 + 0], w1 = tw[s * 4 + 1], w2 = tw[s * 4 + 2], w3 = tw[s * 4 + 3];
+            const int ch = c0 + 4 * lc;
+            const float4 a0 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 0] * a.c + ch);
+            const float4 a1 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 1] * a.c + ch);
+            const float4 a2 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 2] * a.c + ch);
+            const float4 a3 = *reinterpret_cast<const float4 *>(fimg + (long long)toff[s * 4 + 3] * a.c + ch);
+            float val[4];
+            val[0] = a0.x * w0 + a1.x * w1 + a2.x * w2 + a3.x * w3;
+            val[1] = a0.y * w0 + a1.y * w1 + a2.y * w2 + a3.y * w3;
+            val[2] = a0.z * w0 + a1.z * w1 + a2.z * w2 + a3.z * w3;
+            val[3] = a0.w * w0 + a1.w * w1 + a2.w * w2 + a3.w * w3;
+            h4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                _Float16 p, q;
+                dance::split_half(val[i], p, q);
+                hi[i] = p;
+                lo[i] = q;
+            }
+            char *d = xs + ((lc >> 1) * G::VP + s) * 16 + 8 * (lc & 1);
+            *reinterpret_cast<h4 *>(d) = hi;
+            *reinterpret_cast<h4 *>(d + G::PLANE) = lo;
+        }
+        __syncthreads();
+        mfma16_core_sw<RTG, CT, NST, AD, NB, TERMS>(acc, xs, 0, v,
+                                                    reinterpret_cast<const char *>(a.w) + ((long long)(c0 >> 3) * 128 + o0) * 16,
+                                                    wlane, wps_b, wts_b, 4 * wbs_b, 9, 1, c16, q4, 0, nohook);
+    }
+
+    // epilogue: lane = vertex column 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3
+    _Float16 *yslot = a.y + nn * a.y_stride;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int ob = o0 + 16 * i2 + 4 * q4;
+        const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale + ob);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift + ob);
+        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int vv = j * 16 + c16;
+            if (vv >= v)
+                continue;
+            float val[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                val[i] = relu_nan(acc[i2][j][i] * a.winv) * sc[i] + sh[i];
+            dance::store_p16(yslot, v, ob >> 3, vv, (ob >> 2) & 1, val);
+        }
+    }
+}
+
+template <int RTG, int CT>
+int launch_head(const Head16Args &a, int n, int terms, size_t lds, hipStream_t s)
+{
+    int rc;
+    if (terms == 1) {
+        if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 1>, lds, "dance_gather_head16w")))
+            return rc;
+        hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 1>), dim3(n), dim3(256), lds, s, a);
+    } else {
+        if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 3>, lds, "dance_gather_head16w")))
+            return rc;
+        hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 3>), dim3(n), dim3(256), lds, s, a);
+    }
+    return launch_check("dance_gather_head16w");
+}
+
+}  // namespace
+
+extern "C" int dance_gather_head16w(const float *feat, const float *att, const float *loc,
+                                    const int32_t *image_idx, const void *w16, const void *wd16,
+                                    const float *bias_scaled, float w_inv_scale, const float *scale,
+                                    const float *shift, void *y16, int64_t y_stride, float *att_out, int n,
+                                    int v, int b, int hf, int wf, int c, int padding_mode, int deloc_type,
+                                    int mfma_terms, void *stream)
+{
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    // 14 and more column tiles do not fit the register file beside the rotating operand buffers:
+    // rings above 208 vertices stay on k_gather_head16 (224 / 256 columns either way)
+    DANCE_REQUIRE(n >= 0 && v >= 16 && v <= DANCE_HEAD16W_MAX_V);
+    DANCE_REQUIRE(b >= 1 && hf >= 1 && wf >= 1 && (long long)hf * wf < (1ll << 30));
+    DANCE_REQUIRE(c >= 64 && c % 64 == 0);
+    DANCE_REQUIRE(padding_mode == DANCE_PAD_ZEROS || padding_mode == DANCE_PAD_REFLECTION);
+    DANCE_REQUIRE(deloc_type >= DANCE_DELOC_DERANGE && deloc_type <= DANCE_DELOC_NONE);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(feat && loc && w16 && bias_scaled && scale && shift && y16);
+    DANCE_REQUIRE(deloc_type == DANCE_DELOC_NONE || wd16 != nullptr);
+    Head16Args a;
+    a.feat = feat; a.att = att; a.loc = loc; a.image_idx = image_idx; a.att_out = att_out; a.b = b;
+    a.hf = hf; a.wf = wf; a.c = c; a.reflection = padding_mode == DANCE_PAD_REFLECTION; a.deloc = deloc_type;
+    a.w = (const h8 *)w16; a.cin = (c + (deloc_type != DANCE_DELOC_NONE ? 2 : 0) + 31) & ~31;
+    a.wd = (const h8 *)wd16; a.bias_s = bias_scaled; a.scale = scale; a.shift = shift; a.winv = w_inv_scale;
+    a.y = (_Float16 *)y16; a.y_stride = y_stride; a.v = v;
+    const int rtg = v <= 64 ? 2 : (v <= 128 ? 4 : 7);
+    const size_t lds = (size_t)2 * 8 * (rtg * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
+    const int ct = (v + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (rtg == 2)
+        return ct <= 2 ? launch_head<2, 2>(a, n, mfma_terms, lds, s)
+                       : (ct == 3 ? launch_head<2, 3>(a, n, mfma_terms, lds, s) : launch_head<2, 4>(a, n, mfma_terms, lds, s));
+    if (rtg == 4)
+        return ct <= 6 ? launch_head<4, 6>(a, n, mfma_terms, lds, s) : launch_head<4, 8>(a, n, mfma_terms, lds, s);
+    if (ct <= 10)
+        return launch_head<7, 10>(a, n, mfma_terms, lds, s);
+    if (ct <= 12)
+        return launch_head<7, 12>(a, n, mfma_terms, lds, s);
+    return launch_head<7, 13>(a, n, mfma_terms, lds, s);
+}

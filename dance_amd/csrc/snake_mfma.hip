@@ -766,11 +766,18 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
     // opt-in (DANCE_HEAD_STACK=1): measured no faster than the two launches (experiments)
     static const int use_head_stack = getenv("DANCE_HEAD_STACK") ? atoi(getenv("DANCE_HEAD_STACK")) : 0;
     const bool head_stack = x_in == nullptr && use_stack && use_head_stack && v <= 128;
+    // head block on 16-wide vertex tiles (head16.hip); DANCE_HEAD_SHAPE=32: k_gather_head16
+    static const int head_shape16 = (getenv("DANCE_HEAD_SHAPE") ? atoi(getenv("DANCE_HEAD_SHAPE")) : 16) == 16;
     if (head_stack) {
         // gather + head block + the 7 residual blocks in one launch; its time is booked on stage head
         DANCE_TRY(dance_head_stack16(net, feat, att, loc, image_idx, state, sstride, slot,
                                      use_att ? w.att_s : nullptr, n, v, b, hf, wf, padding_mode, deloc_type,
                                      mfma_terms, stream));
+    } else if (x_in == nullptr && net->head_wd != nullptr && head_shape16 && v <= DANCE_HEAD16W_MAX_V) {
+        DANCE_TRY(dance_gather_head16w(feat, att, loc, image_idx, net->head_w, net->head_wd, net->head_bs,
+                                       net->head_winv, net->head_scale, net->head_shift, state, sstride,
+                                       use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
+                                       deloc_type, mfma_terms, stream));
     } else if (x_in == nullptr) {
         DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
                                       net->head_winv, net->head_scale, net->head_shift, state, sstride,

@@ -124,7 +124,7 @@ def pack_conv_weight(weight):
     return w.contiguous()
 
 
-def pack_conv_weight16(weight):
+def pack_conv_weight16(weight, scale=None):
     """Conv1d weight (Cout, Cin, K) -> split-half packing for the fast precision mode:
     (2, K, Cin_pad32/8, Cout, 8) fp16 = hi/lo planes of w * 2^s, plus 2^s.  The power-of-two
     scale keeps the lo halves normal fp16 numbers and is undone exactly in the epilogue.
@@ -135,6 +135,8 @@ def pack_conv_weight16(weight):
     w[:, :cin, :] = weight.float()
     amax = float(w.abs().max())
     s = 2.0 ** math.floor(math.log2(1024.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+    if scale is not None:               # a slice of a tensor packed elsewhere: that tensor's scale
+        s = float(scale)
     ws = w * s
     hi = ws.half()
     lo = (ws - hi.float()).half()

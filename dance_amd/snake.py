@@ -100,6 +100,14 @@ class SnakeNetWeights:
 
         s.head_w, s.head_winv = pack("head", sdd["head.conv.fc.weight"], sdd["head.conv.fc.bias"])
         s.head_bs = t["head_bs"].data_ptr()
+        # the two de_location input channels of the head block as one 32-deep K step (head16.hip):
+        # k = 0..8 the 9 ring taps of dx, 9..17 of dy, the rest zero; the head's scale
+        hw = sdd["head.conv.fc.weight"]                                           # (128, C + 2, 9)
+        wd = torch.zeros((hw.shape[0], 32, 1), dtype=torch.float32, device=hw.device)
+        wd[:, 0:9, 0] = hw[:, -2, :]
+        wd[:, 9:18, 0] = hw[:, -1, :]
+        t["head_wd16"], _ = ops.pack_conv_weight16(wd, scale=scales["head"])
+        s.head_wd = t["head_wd16"].data_ptr()
         s.head_scale, s.head_shift = t["head_scale"].data_ptr(), t["head_shift"].data_ptr()
         for i in range(7):
             n = "res%d" % i

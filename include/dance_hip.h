@@ -457,6 +457,20 @@ int dance_gather_head16(const float *feat, const float *att, const float *loc,
                         int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf, int c,
                         int padding_mode, int deloc_type, int mfma_terms, void *stream);
 
+/* dance_gather_head16 on 16-wide vertex tiles (v_mfma_f32_16x16x32_f16): the ring is padded to a
+ * multiple of 16 columns instead of 32 (196 vertices: 208 instead of 224), and the two de_location
+ * channels are one K step (wd16, see dance_snake_net16.head_wd) instead of a zero-padded chunk
+ * through all 9 ring taps.  v <= DANCE_HEAD16W_MAX_V (longer rings: dance_gather_head16, whose 224 /
+ * 256 columns they fill anyway).  Same results up to summation order.  reference: as dance_gather_head16
+ * (snake_head.py:1542-1572, 1587-1610, 1639-1652, _SnakeNet.head :233). */
+#define DANCE_HEAD16W_MAX_V 208
+int dance_gather_head16w(const float *feat, const float *att, const float *loc,
+                         const int32_t *image_idx, const void *w16, const void *wd16,
+                         const float *bias_scaled, float w_inv_scale, const float *scale,
+                         const float *shift, void *y16, int64_t y_stride, float *att_out, int n, int v,
+                         int b, int hf, int wf, int c, int padding_mode, int deloc_type, int mfma_terms,
+                         void *stream);
+
 /* The same head block on a precomputed fp32 input x_in (n, c + 2, v), contour stride x_stride
  * floats, instead of the gather: DsnakeHead.init's input, the fused [sampled | centre] features
  * plus the two de_location channels (dsnake_head.py:718-741). */
@@ -497,6 +511,10 @@ typedef struct dance_snake_net16 {
     float head_winv, res_winv[7], fuse_winv, pred1_winv;
     int dilation[7];
     int feat_channels;
+    const void *head_wd;        /* the head block's two de_location input channels as one 32-deep
+                                   K step: (2,1,4,128,8) packing of W'[o][k], k = 9 ring taps of dx,
+                                   9 of dy, 14 zeros, with head_w's scale (dance_gather_head16w);
+                                   null: dance_snake_evolve16 uses dance_gather_head16 */
 } dance_snake_net16;
 
 /* The 7 residual SnakeBlocks (res_* fields of the net) in one launch, v <= 256: state is the

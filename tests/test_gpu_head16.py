@@ -1,0 +1,96 @@
+"""dance_gather_head16w (gather + de_location + head block on 16-wide vertex tiles, the
+de_location channels as one im2col K step -- csrc/head16.hip) against dance_gather_head16 (32-wide
+tiles, same arithmetic up to summation order) and against plain torch fp32 -- reference:
+RefineNet.evolve snake_head.py:1639-1652, _SnakeNet.head :233."""
+import pytest
+import torch
+
+from dance_amd import ops, snake, synthetic
+from dance_amd._lib import check, current_stream, lib, ptr
+from _util import dance_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fn_name, s16, nhwc, att, loc, idx, n, v, pad, deloc, terms, use_att=True):
+    dev = nhwc.device
+    b, hf, wf, c = nhwc.shape
+    y = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=dev)
+    att_o = torch.zeros((n, v), device=dev)
+    with torch.cuda.device(dev):
+        st = current_stream()
+        extra = (s16.head_wd,) if fn_name == "dance_gather_head16w" else ()
+        check(getattr(lib(), fn_name)(ptr(nhwc), ptr(att) if use_att else None, ptr(loc), ptr(idx), s16.head_w, *extra,
+                                      s16.head_bs, s16.head_winv, s16.head_scale, s16.head_shift, ptr(y), y.stride(0),
+                                      ptr(att_o) if use_att else None, n, v, b, hf, wf, c, pad, deloc, terms, st),
+              fn_name)
+    return ops.from_p16(y[:, :1].contiguous()), att_o
+
+
+def _inputs(device, v, n=29, seed=5):
+    b, hf, wf = 2, 40, 56
+    feats = synthetic.make_features(b, 256, hf, wf, seed).to(device)
+    nhwc, att = ops.nchw_to_nhwc(feats, 1)
+    boxes = synthetic.make_boxes(n, hf * 4, wf * 4, v, r_min=6, r_max=50)
+    loc = synthetic.make_circle_contours(boxes, v).to(device)
+    loc[3] += 400.0                                             # leaves the image
+    idx = (torch.arange(n) % b).to(torch.int32).to(device)
+    return nhwc, att, loc, idx
+
+
+@pytest.mark.parametrize("v", [16, 20, 32, 36, 40, 48, 64, 68, 96, 100, 128, 132, 160, 164, 192, 196, 208])
+def test_head16w_equals_head16(device, v):
+    cfg, sd, _ = dance_state_dict(77, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer2."), device)
+    s16 = net.struct16
+    nhwc, att, loc, idx = _inputs(device, v)
+    n = loc.shape[0]
+    for terms, pad, deloc in [(3, ops.PAD_REFLECTION, "derange"), (1, ops.PAD_REFLECTION, "derange"),
+                              (3, ops.PAD_ZEROS, "demin"), (3, ops.PAD_REFLECTION, "demean")]:
+        a, att_a = _run("dance_gather_head16w", s16, nhwc, att, loc, idx, n, v, pad, ops.DELOC[deloc], terms)
+        b, att_b = _run("dance_gather_head16", s16, nhwc, att, loc, idx, n, v, pad, ops.DELOC[deloc], terms)
+        scale = float(b.abs().max())
+        assert scale > 0 and bool(torch.isfinite(a).all())
+        tol = 1e-5 if terms == 3 else 5e-3                      # summation order (one term: fp16 operands)
+        assert float((a - b).abs().max()) <= tol * scale, (v, terms, deloc)
+        assert torch.equal(att_a, att_b)
+
+
+def test_head16w_vs_torch(device):
+    """torch fp32: grid_sample (reflection) -> derange de_location -> circular Conv1d k = 9 -> ReLU ->
+    BatchNorm (eval), from the same weights."""
+    cfg, sd, _ = dance_state_dict(78, 128)
+    sub = snake.sub_state_dict(sd, "deformer0.")
+    net = snake.SnakeNetWeights(sub, device)
+    v = 196
+    nhwc, att, loc, idx = _inputs(device, v, n=13, seed=9)
+    n = loc.shape[0]
+    got, _ = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, n, v, ops.PAD_REFLECTION,
+                  ops.DELOC["derange"], 3)
+    sampled, _ = ops.gather_features(nhwc, att, loc, idx, ops.PAD_REFLECTION, "derange")      # (n, 258, v) exact fp32
+    w = {k: t.to(device).float() for k, t in sub.items()}
+    x = torch.cat([sampled[:, :, -4:], sampled, sampled[:, :, :4]], dim=2)
+    y = torch.relu(torch.nn.functional.conv1d(x, w["head.conv.fc.weight"], w["head.conv.fc.bias"]))
+    want = torch.nn.functional.batch_norm(y, w["head.norm.running_mean"], w["head.norm.running_var"],
+                                          w["head.norm.weight"], w["head.norm.bias"], False, 0.0, 1e-5)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_head16w_no_deloc_and_no_attention(device):
+    cfg, sd, _ = dance_state_dict(79, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
+    v = 100
+    nhwc, att, loc, idx = _inputs(device, v)
+    n = loc.shape[0]
+    a, _ = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, n, v, ops.PAD_ZEROS, ops.DELOC[None], 3, False)
+    b, _ = _run("dance_gather_head16", net.struct16, nhwc, att, loc, idx, n, v, ops.PAD_ZEROS, ops.DELOC[None], 3, False)
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_head16w_rejects_long_rings(device):
+    cfg, sd, _ = dance_state_dict(79, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
+    nhwc, att, loc, idx = _inputs(device, 224)
+    with pytest.raises(RuntimeError):
+        _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, loc.shape[0], 224, ops.PAD_ZEROS,
+             ops.DELOC["demin"], 3)
