@@ -131,7 +131,7 @@ SIGNATURES = {
     "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int, P]),
     "dance_head_stack16": (c_int, [POINTER(SnakeNet16Struct), P, P, P, P, P, c_int64, c_int64, P, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dance_init_head16": (c_int, [P, P, P, P, c_float, P, P, P, P, c_float, P, P, P, c_int64, c_int, c_int,
+    "dance_init_head16": (c_int, [P, P, P, P, c_float, P, P, P, P, P, c_float, P, P, P, c_int64, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_snake_init16": (c_int, [POINTER(SnakeNet16Struct), POINTER(InitFuse16Struct), P, P, P, P, P,
                                    c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -29,7 +29,8 @@ struct InitHead16Args {
     const h8 *fw;                 // fuse, sampled half: [plane][1][32][256] words
     float fwinv;
     const float *fwg, *fb;        // fuse, centre half [g][o] (256, 256); bias (256)
-    const h8 *hw;                 // head block: [plane][9][36][128] words (258 -> 288 channels)
+    const h8 *hw;                 // head block: [plane][9][36][128] words (258 -> 288 channels; feature blocks used)
+    const h8 *hwd;                // head block, de_location channels as one K step: [plane][4][128] words (head16.hip)
     const float *hbs, *hscale, *hshift;
     float hwinv;
     _Float16 *y;                  // state slot 0 (P16)
@@ -37,10 +38,12 @@ struct InitHead16Args {
     int v;
 };
 
-template <int RT, int TERMS>
+// CT: 16-wide vertex tiles of the head block (3 for Dsnake's 40-point ring)
+template <int RT, int CT, int TERMS>
 __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
 {
     constexpr int C = 256, NCH = C / 64;
+    static_assert(CT * 16 <= RT * 32, "the column tiles fit the image");
     using G = Geo<RT, 8>;
     using GD = Geo<RT, 4>;                                      // de_location chunk: 32 channels
     static_assert(4 * 256 * 4 + 256 * 4 + 2 * (RT * 32 + 1) * 16 <= GD::BYTES, "scratch under the de_location image");
@@ -204,54 +207,90 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
                 }
             }
     }
-    // de_location chunk: block 0 = {dx, dy, 0 x 6}, blocks 1..3 = zeros (weights zero-padded)
+    // de_location as one K step (head16.hip): word (block kb, vertex vi) = entries 8 kb .. 8 kb + 7 of
+    // [dx(vi - 4 .. vi + 4), dy(vi - 4 .. vi + 4), 0 x 14]
     if (a.deloc != DANCE_DELOC_NONE)
         for (int i = t; i < 4 * v; i += 256) {
-            const int blk = i / v, vi = i - blk * v;
+            const int kb = i / v, vi = i - kb * v;
             h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (blk == 0) {
-                _Float16 p, q;
-                dance::split_half(dl[vi], p, q);
-                hi[0] = p; lo[0] = q;
-                dance::split_half(dl[RT * 32 + vi], p, q);
-                hi[1] = p; lo[1] = q;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb * 8 + e;
+                if (k < 18) {
+                    const int ch = k >= 9, tap = k - 9 * ch;
+                    _Float16 p, q;
+                    dance::split_half(dl[ch * RT * 32 + ring16(vi, tap - 4, v)], p, q);
+                    hi[e] = p;
+                    lo[e] = q;
+                }
             }
-            *reinterpret_cast<h8 *>(dimg + (blk * GD::VP + vi) * 16) = hi;
-            *reinterpret_cast<h8 *>(dimg + GD::PLANE + (blk * GD::VP + vi) * 16) = lo;
+            *reinterpret_cast<h8 *>(dimg + (kb * GD::VP + vi) * 16) = hi;
+            *reinterpret_cast<h8 *>(dimg + GD::PLANE + (kb * GD::VP + vi) * 16) = lo;
         }
     __syncthreads();
 
-    // ---- head block: CircConv k = 9 over [x | de_location], ReLU, BatchNorm
+    // ---- head block on 16-wide vertex tiles: CircConv k = 9 over x, one K step for de_location,
+    //      ReLU, BatchNorm
+    const int c16 = lane & 15, q4 = lane >> 4;
     const int o0 = wave * 32;
-    f32x16 acc[1][RT];
-    init_acc16<RT, 1>(acc, a.hbs, o0, h, 1.0f);
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.hbs + o0 + 16 * i + 4 * q4);
+        const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+            acc[i][j] = bv;
+    }
+    if (a.deloc != DANCE_DELOC_NONE) {
+        h8 ah[2], al[2];
+        const char *wdp = reinterpret_cast<const char *>(a.hwd) + (unsigned)(q4 * 128 + o0 + c16) * 16u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const h8 *>(wdp + i * 256);
+            if constexpr (TERMS == 3)
+                al[i] = *reinterpret_cast<const h8 *>(wdp + 4 * 128 * 16 + i * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const char *bq = dimg + (unsigned)(q4 * GD::VP + min(j * 16 + c16, v - 1)) * 16u;
+            const h8 bh = *reinterpret_cast<const h8 *>(bq);
+            if constexpr (TERMS == 3) {
+                const h8 bl = *reinterpret_cast<const h8 *>(bq + GD::PLANE);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], bh, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], bh, acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bl, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bl, acc[1][j], 0, 0, 0);
+            }
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bh, acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bh, acc[1][j], 0, 0, 0);
+        }
+    }
     const int cin = a.deloc != DANCE_DELOC_NONE ? C + 32 : C;
     const long long wbs_b = 128ll * 16, wts_b = (long long)(cin >> 3) * wbs_b, wps_b = 9 * wts_b;
-    const unsigned wlane = (unsigned)(h * 128 + r) * 16u;
+    const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
+    constexpr int NB = (2 * CT) % 4 == 0 && CT >= 3 ? 4 : 2;
     for (int ch = 0; ch < NCH; ++ch)
-        mfma16_core<RT, 1, 4, 4, 4, TERMS>(acc, img + ch * G::BYTES, 0, v,
-                                           reinterpret_cast<const char *>(a.hw) + ((long long)(ch * 8) * 128 + o0) * 16,
-                                           wlane, wps_b, wts_b, 2 * wbs_b, 9, 1, r, h, nohook);
-    if (a.deloc != DANCE_DELOC_NONE)
-        mfma16_core<RT, 1, 2, 2, 2, TERMS>(acc, dimg, 0, v,
-                                           reinterpret_cast<const char *>(a.hw) + ((long long)(C >> 3) * 128 + o0) * 16,
-                                           wlane, wps_b, wts_b, 2 * wbs_b, 9, 1, r, h, nohook);
+        mfma16_core_sw<RT, CT, 2, 2, NB, TERMS>(acc, img + ch * G::BYTES, 0, v,
+                                                reinterpret_cast<const char *>(a.hw) + ((long long)(ch * 8) * 128 + o0) * 16,
+                                                wlane, wps_b, wts_b, 4 * wbs_b, 9, 1, c16, q4, 0, nohook);
     _Float16 *yslot = a.y + nn * a.y_stride;
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        const float4 sc4 = *reinterpret_cast<const float4 *>(a.hscale + o0 + 8 * gq + 4 * h);
-        const float4 sh4 = *reinterpret_cast<const float4 *>(a.hshift + o0 + 8 * gq + 4 * h);
+    for (int i2 = 0; i2 < 2; ++i2) {
+        const int ob = o0 + 16 * i2 + 4 * q4;
+        const float4 sc4 = *reinterpret_cast<const float4 *>(a.hscale + ob);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(a.hshift + ob);
         const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int vv = rt * 32 + r;
+        for (int j = 0; j < CT; ++j) {
+            const int vv = j * 16 + c16;
             if (vv >= v)
                 continue;
             float val[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                val[i] = relu_nan(acc[0][rt][4 * gq + i] * a.hwinv) * sc[i] + sh[i];
-            dance::store_p16(yslot, v, (o0 >> 3) + gq, vv, h, val);
+                val[i] = relu_nan(acc[i2][j][i] * a.hwinv) * sc[i] + sh[i];
+            dance::store_p16(yslot, v, ob >> 3, vv, (ob >> 2) & 1, val);
         }
     }
 }
@@ -260,7 +299,8 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
 
 extern "C" int dance_init_head16(const float *feat, const float *loc, const int32_t *image_idx,
                                  const void *fuse_w16, float fuse_w_inv_scale, const float *fuse_wg,
-                                 const float *fuse_bias, const void *head_w16, const float *head_bias_scaled,
+                                 const float *fuse_bias, const void *head_w16, const void *head_wd16,
+                                 const float *head_bias_scaled,
                                  float head_w_inv_scale, const float *head_scale, const float *head_shift,
                                  void *y16, int64_t y_stride, int n, int v, int b, int hf, int wf, int c,
                                  int padding_mode, int deloc_type, int mfma_terms, void *stream)
@@ -273,25 +313,32 @@ extern "C" int dance_init_head16(const float *feat, const float *loc, const int3
     DANCE_REQUIRE(deloc_type >= DANCE_DELOC_DERANGE && deloc_type <= DANCE_DELOC_NONE);
     if (n == 0)
         return 0;
-    DANCE_REQUIRE(feat && loc && fuse_w16 && fuse_wg && fuse_bias && head_w16 && head_bias_scaled &&
+    DANCE_REQUIRE(feat && loc && fuse_w16 && fuse_wg && fuse_bias && head_w16 && head_wd16 && head_bias_scaled &&
                   head_scale && head_shift && y16);
     InitHead16Args a;
     a.feat = feat; a.loc = loc; a.image_idx = image_idx; a.b = b; a.hf = hf; a.wf = wf;
     a.reflection = padding_mode == DANCE_PAD_REFLECTION; a.deloc = deloc_type;
     a.fw = (const h8 *)fuse_w16; a.fwinv = fuse_w_inv_scale; a.fwg = fuse_wg; a.fb = fuse_bias;
-    a.hw = (const h8 *)head_w16; a.hbs = head_bias_scaled; a.hscale = head_scale; a.hshift = head_shift;
+    a.hw = (const h8 *)head_w16; a.hwd = (const h8 *)head_wd16; a.hbs = head_bias_scaled; a.hscale = head_scale; a.hshift = head_shift;
     a.hwinv = head_w_inv_scale; a.y = (_Float16 *)y16; a.y_stride = y_stride; a.v = v;
     constexpr int RT = 2;
     const size_t lds = (size_t)4 * Geo<RT, 8>::BYTES + Geo<RT, 4>::BYTES + (256 + 2 * RT * 32 + 16) * sizeof(float);
-    int rc;
-    if (mfma_terms == 1) {
-        if ((rc = dance::allow_lds((const void *)k_init_head16<RT, 1>, lds, __func__)))
-            return rc;
-        hipLaunchKernelGGL((k_init_head16<RT, 1>), dim3(n), dim3(256), lds, (hipStream_t)stream, a);
-    } else {
-        if ((rc = dance::allow_lds((const void *)k_init_head16<RT, 3>, lds, __func__)))
-            return rc;
-        hipLaunchKernelGGL((k_init_head16<RT, 3>), dim3(n), dim3(256), lds, (hipStream_t)stream, a);
-    }
+    int rc = 0;
+#define INIT_LAUNCH(CTV, T)                                                                        \
+    do {                                                                                           \
+        if (!(rc = dance::allow_lds((const void *)k_init_head16<RT, CTV, T>, lds, __func__)))      \
+            hipLaunchKernelGGL((k_init_head16<RT, CTV, T>), dim3(n), dim3(256), lds, (hipStream_t)stream, a); \
+    } while (0)
+    if (v <= 48 && mfma_terms == 1)
+        INIT_LAUNCH(3, 1);
+    else if (v <= 48)
+        INIT_LAUNCH(3, 3);
+    else if (mfma_terms == 1)
+        INIT_LAUNCH(4, 1);
+    else
+        INIT_LAUNCH(4, 3);
+#undef INIT_LAUNCH
+    if (rc)
+        return rc;
     return launch_check(__func__);
 }

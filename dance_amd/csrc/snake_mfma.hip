@@ -808,14 +808,14 @@ extern "C" int dance_snake_init16(const dance_snake_net16 *net, const dance_init
         return 0;
     DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr && feat != nullptr);
     DANCE_REQUIRE(v >= 16 && v <= 64 && v % 4 == 0);
-    DANCE_REQUIRE(net->feat_channels == 256);
+    DANCE_REQUIRE(net->feat_channels == 256 && net->head_wd != nullptr);
     Workspace w = carve(workspace, n, v, 272);
     DANCE_REQUIRE(workspace_bytes >= w.bytes);
     StageMarks mark{stage_events_host, stream, "dance_snake_init16"};
     DANCE_TRY(mark());
     DANCE_TRY(dance_init_head16(feat, loc, image_idx, fuse->w16, fuse->w_inv_scale, fuse->wg_center, fuse->bias,
-                                net->head_w, net->head_bs, net->head_winv, net->head_scale, net->head_shift,
-                                w.state, 2048ll * v, n, v, b, hf, wf, 256, padding_mode, deloc_type, mfma_terms,
+                                net->head_w, net->head_wd, net->head_bs, net->head_winv, net->head_scale,
+                                net->head_shift, w.state, 2048ll * v, n, v, b, hf, wf, 256, padding_mode, deloc_type, mfma_terms,
                                 stream));
     DANCE_TRY(mark());
     return evolve16_after_head(net, w, false, loc, nullptr, nullptr, out, n, v, 0, 0.0f, 0.0f, mfma_terms,

@@ -482,12 +482,14 @@ int dance_xin_head16(const float *x_in, int64_t x_stride, const void *w16, const
  * bilinear gather at the ring's vertices and at its centre (min + max) / 2, fuse Conv1d(2c -> c,
  * k = 1) with the centre half folded into a per-contour row constant (fuse_w16: the sampled half
  * packed (2,1,32,256,8) with inverse scale fuse_w_inv_scale; fuse_wg: the centre half as [g][o]
- * (256,256) fp32; fuse_bias (256)), de_location, head SnakeBlock -> slot 0 of a P16 block.
+ * (256,256) fp32; fuse_bias (256)), de_location, head SnakeBlock on 16-wide vertex tiles (head_w16 /
+ * head_wd16 as in dance_gather_head16w) -> slot 0 of a P16 block.
  * reference: DsnakeHead.init dsnake_head.py:718-736 (+ get_locations_feature :678-695,
  * de_location :697-708, _SnakeNet.head :99, :120). */
 int dance_init_head16(const float *feat, const float *loc, const int32_t *image_idx,
                       const void *fuse_w16, float fuse_w_inv_scale, const float *fuse_wg,
-                      const float *fuse_bias, const void *head_w16, const float *head_bias_scaled,
+                      const float *fuse_bias, const void *head_w16, const void *head_wd16,
+                      const float *head_bias_scaled,
                       float head_w_inv_scale, const float *head_scale, const float *head_shift,
                       void *y16, int64_t y_stride, int n, int v, int b, int hf, int wf, int c,
                       int padding_mode, int deloc_type, int mfma_terms, void *stream);
