@@ -706,6 +706,9 @@ def main():
                     "k_conv16s" if rt <= 4 else "k_conv16<", n_ev)
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"
             gkernel = ("k_head_stack16s<%d> (fused gather + head SnakeBlock + residual stack)" % rt if head_stack
+                       else "k_gather_head16w<%d,%d> (fused gather + head SnakeBlock, 16-wide vertex tiles)" % (
+                           2 if v <= 64 else 4 if v <= 128 else 7, -(-v // 16))
+                       if v <= 208 and os.environ.get("DANCE_HEAD_SHAPE", "16") == "16"
                        else "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt)
         else:
             roof = {"kernel": "k_circconv<%d> (residual SnakeBlock 128->128, k=9, f32 MFMA)" % rt,

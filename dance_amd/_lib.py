@@ -123,7 +123,7 @@ SIGNATURES = {
                                  c_int, P]),
     "dance_tail16": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int,
                              c_int, c_int, c_float, c_float, c_int, P]),
-    "dance_gather_head16": (c_int, [P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
+    "dance_gather_head16": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "dance_gather_head16w": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

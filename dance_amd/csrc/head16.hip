@@ -233,9 +233,14 @@ extern "C" int dance_gather_head16w(const float *feat, const float *att, const f
                                     int mfma_terms, void *stream)
 {
     DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
     // 14 and more column tiles do not fit the register file beside the rotating operand buffers:
-    // rings above 208 vertices stay on k_gather_head16 (224 / 256 columns either way)
-    DANCE_REQUIRE(n >= 0 && v >= 16 && v <= DANCE_HEAD16W_MAX_V);
+    // rings above 208 vertices run k_gather_head16 (224 / 256 columns either way) with the same
+    // de_location K step
+    if (v > DANCE_HEAD16W_MAX_V)
+        return dance_gather_head16(feat, att, loc, image_idx, w16, wd16, bias_scaled, w_inv_scale, scale, shift,
+                                   y16, y_stride, att_out, n, v, b, hf, wf, c, padding_mode, deloc_type,
+                                   mfma_terms, stream);
     DANCE_REQUIRE(b >= 1 && hf >= 1 && wf >= 1 && (long long)hf * wf < (1ll << 30));
     DANCE_REQUIRE(c >= 64 && c % 64 == 0);
     DANCE_REQUIRE(padding_mode == DANCE_PAD_ZEROS || padding_mode == DANCE_PAD_REFLECTION);

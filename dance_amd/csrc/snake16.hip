@@ -1003,6 +1003,9 @@ struct Gather16Args {
     int b, hf, wf, c, reflection, deloc;
     const float *x_in;          // XIN flavour: precomputed (c + 2, v) fp32 input per contour instead of
     long long x_stride;         // the gather (Dsnake init: fused features + de_location channels)
+    const h8 *wd;               // de_location channels as ONE 32-deep K step (head16.hip: the 2 x 9
+                                // (channel, tap) pairs as an im2col column per vertex, weights
+                                // [plane][4][128] words), or null: zero-padded 32-channel chunk, 9 taps
 };
 
 // TO_LDS: the workgroup goes on with the residual stack (k_head_stack16s): two chunk images are
@@ -1123,7 +1126,31 @@ __device__ __forceinline__ void gather_head16_body(const Conv16Args &a, const Ga
                                  reinterpret_cast<const char *>(a.w) + ((long long)(c0 >> 3) * a.cout + o0) * 16,
                                  wlane, wps_b, wts_b, 2 * wbs_b, a.taps, a.dilation, r, h, nohook);
     }
-    if (g.deloc != DANCE_DELOC_NONE) {
+    if (g.deloc != DANCE_DELOC_NONE && g.wd != nullptr) {
+        // word (block kb, vertex vi) = entries 8 kb .. 8 kb + 7 of
+        // [dx(vi - 4 .. vi + 4), dy(vi - 4 .. vi + 4), 0 x 14]; no ring taps left
+        __syncthreads();
+        for (int i = t; i < 4 * v; i += 256) {
+            const int kb = i / v, vi = i - kb * v;
+            h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb * 8 + e;
+                if (k < 18) {
+                    const int ch = k >= 9, tap = k - 9 * ch;
+                    _Float16 p, q;
+                    dance::split_half(dl[ch * v + ring16(vi, tap - 4, v)], p, q);
+                    hi[e] = p;
+                    lo[e] = q;
+                }
+            }
+            *reinterpret_cast<h8 *>(xs + (kb * GD::VP + vi) * 16) = hi;
+            *reinterpret_cast<h8 *>(xs + GD::PLANE + (kb * GD::VP + vi) * 16) = lo;
+        }
+        __syncthreads();
+        mfma16_core<RT, 1, 2, 2, 2, TERMS>(acc, xs, 0, v, reinterpret_cast<const char *>(g.wd) + (long long)o0 * 16,
+                                 wlane, 4 * wbs_b, 4 * wbs_b, 2 * wbs_b, 1, 1, r, h, nohook);
+    } else if (g.deloc != DANCE_DELOC_NONE) {
         // de_location chunk: 4 blocks (weights zero-padded to 32 channels);
         // block 0 = {dx, dy, 0 x 6}, blocks 1..3 = zeros
         __syncthreads();
@@ -1384,7 +1411,7 @@ extern "C" int dance_head_stack16(const dance_snake_net16 *net, const float *fea
     Gather16Args g;
     g.feat = feat; g.att = att; g.loc = loc; g.image_idx = image_idx; g.att_out = att_out; g.b = b;
     g.hf = hf; g.wf = wf; g.c = c; g.reflection = padding_mode == DANCE_PAD_REFLECTION;
-    g.deloc = deloc_type; g.x_in = nullptr; g.x_stride = 0;
+    g.deloc = deloc_type; g.x_in = nullptr; g.x_stride = 0; g.wd = nullptr;
     Stack16Args st;
     st.state = (_Float16 *)state; st.stride = stride; st.slot = slot; st.v = v; st.nlayers = 7;
     for (int i = 0; i < 7; ++i) {
@@ -1511,7 +1538,7 @@ extern "C" int dance_xin_head16(const float *x_in, int64_t x_stride, const void 
     Gather16Args g;
     g.feat = nullptr; g.att = nullptr; g.loc = x_in; g.image_idx = nullptr; g.att_out = nullptr; g.b = 1;
     g.hf = 1; g.wf = 1; g.c = c; g.reflection = 0; g.deloc = DANCE_DELOC_DEMIN;
-    g.x_in = x_in; g.x_stride = x_stride;
+    g.x_in = x_in; g.x_stride = x_stride; g.wd = nullptr;
     const int rt = pick_rt16(v);
     const size_t lds = (size_t)2 * 8 * (rt * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
     LAUNCH_RT(k_xin_head16, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream, "dance_xin_head16", a, g);
@@ -1519,7 +1546,8 @@ extern "C" int dance_xin_head16(const float *x_in, int64_t x_stride, const void 
 }
 
 extern "C" int dance_gather_head16(const float *feat, const float *att, const float *loc,
-                                   const int32_t *image_idx, const void *w16, const float *bias_scaled,
+                                   const int32_t *image_idx, const void *w16, const void *wd16,
+                                   const float *bias_scaled,
                                    float w_inv_scale, const float *scale, const float *shift, void *y16,
                                    int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf,
                                    int c, int padding_mode, int deloc_type, int mfma_terms, void *stream)
@@ -1543,7 +1571,7 @@ extern "C" int dance_gather_head16(const float *feat, const float *att, const fl
     g.feat = feat; g.att = att; g.loc = loc; g.image_idx = image_idx; g.att_out = att_out; g.b = b;
     g.hf = hf; g.wf = wf; g.c = c; g.reflection = padding_mode == DANCE_PAD_REFLECTION;
     g.deloc = deloc_type;
-    g.x_in = nullptr; g.x_stride = 0;
+    g.x_in = nullptr; g.x_stride = 0; g.wd = (const h8 *)wd16;
     const int rt = pick_rt16(v);
     const size_t lds = (size_t)2 * 8 * (rt * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
     LAUNCH_RT(k_gather_head16, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream,

@@ -773,13 +773,13 @@ extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_sn
         DANCE_TRY(dance_head_stack16(net, feat, att, loc, image_idx, state, sstride, slot,
                                      use_att ? w.att_s : nullptr, n, v, b, hf, wf, padding_mode, deloc_type,
                                      mfma_terms, stream));
-    } else if (x_in == nullptr && net->head_wd != nullptr && head_shape16 && v <= DANCE_HEAD16W_MAX_V) {
+    } else if (x_in == nullptr && net->head_wd != nullptr && head_shape16) {
         DANCE_TRY(dance_gather_head16w(feat, att, loc, image_idx, net->head_w, net->head_wd, net->head_bs,
                                        net->head_winv, net->head_scale, net->head_shift, state, sstride,
                                        use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
                                        deloc_type, mfma_terms, stream));
     } else if (x_in == nullptr) {
-        DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, net->head_bs,
+        DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, nullptr, net->head_bs,
                                       net->head_winv, net->head_scale, net->head_shift, state, sstride,
                                       use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
                                       deloc_type, mfma_terms, stream));

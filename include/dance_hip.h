@@ -450,9 +450,12 @@ int dance_tail16(const void *p1, int64_t p1_stride, int64_t p1_slot_stride, cons
                  int clip_first, float clip_x_max, float clip_y_max, int mfma_terms, void *stream);
 
 /* Fused gather + de_location + head SnakeBlock writing slot 0 of a P16 block
- * (as dance_gather_circconv_head; c % 64 == 0). */
+ * (as dance_gather_circconv_head; c % 64 == 0).  wd16: the two de_location channels as one K step
+ * (dance_snake_net16.head_wd), or null: they ride a zero-padded 32-channel chunk through the 9 ring
+ * taps (w16's last channel blocks). */
 int dance_gather_head16(const float *feat, const float *att, const float *loc,
-                        const int32_t *image_idx, const void *w16, const float *bias_scaled,
+                        const int32_t *image_idx, const void *w16, const void *wd16,
+                        const float *bias_scaled,
                         float w_inv_scale, const float *scale, const float *shift, void *y16,
                         int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf, int c,
                         int padding_mode, int deloc_type, int mfma_terms, void *stream);
@@ -460,8 +463,8 @@ int dance_gather_head16(const float *feat, const float *att, const float *loc,
 /* dance_gather_head16 on 16-wide vertex tiles (v_mfma_f32_16x16x32_f16): the ring is padded to a
  * multiple of 16 columns instead of 32 (196 vertices: 208 instead of 224), and the two de_location
  * channels are one K step (wd16, see dance_snake_net16.head_wd) instead of a zero-padded chunk
- * through all 9 ring taps.  v <= DANCE_HEAD16W_MAX_V (longer rings: dance_gather_head16, whose 224 /
- * 256 columns they fill anyway).  Same results up to summation order.  reference: as dance_gather_head16
+ * through all 9 ring taps.  Rings above DANCE_HEAD16W_MAX_V vertices are handed to
+ * dance_gather_head16 with wd16 (224 / 256 columns either way).  Same results up to summation order.  reference: as dance_gather_head16
  * (snake_head.py:1542-1572, 1587-1610, 1639-1652, _SnakeNet.head :233). */
 #define DANCE_HEAD16W_MAX_V 208
 int dance_gather_head16w(const float *feat, const float *att, const float *loc,

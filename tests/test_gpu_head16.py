@@ -12,14 +12,14 @@ from _util import dance_state_dict
 pytestmark = pytest.mark.gpu
 
 
-def _run(fn_name, s16, nhwc, att, loc, idx, n, v, pad, deloc, terms, use_att=True):
+def _run(fn_name, s16, nhwc, att, loc, idx, n, v, pad, deloc, terms, use_att=True, wd32=False):
     dev = nhwc.device
     b, hf, wf, c = nhwc.shape
     y = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=dev)
     att_o = torch.zeros((n, v), device=dev)
     with torch.cuda.device(dev):
         st = current_stream()
-        extra = (s16.head_wd,) if fn_name == "dance_gather_head16w" else ()
+        extra = (s16.head_wd if fn_name == "dance_gather_head16w" or wd32 else None,)
         check(getattr(lib(), fn_name)(ptr(nhwc), ptr(att) if use_att else None, ptr(loc), ptr(idx), s16.head_w, *extra,
                                       s16.head_bs, s16.head_winv, s16.head_scale, s16.head_shift, ptr(y), y.stride(0),
                                       ptr(att_o) if use_att else None, n, v, b, hf, wf, c, pad, deloc, terms, st),
@@ -87,10 +87,23 @@ def test_head16w_no_deloc_and_no_attention(device):
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
 
 
-def test_head16w_rejects_long_rings(device):
-    cfg, sd, _ = dance_state_dict(79, 128)
-    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
-    nhwc, att, loc, idx = _inputs(device, 224)
-    with pytest.raises(RuntimeError):
-        _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, loc.shape[0], 224, ops.PAD_ZEROS,
-             ops.DELOC["demin"], 3)
+@pytest.mark.parametrize("v", [40, 128, 212, 224, 256])
+def test_head16_de_location_k_step_equals_padded_chunk(device, v):
+    """The 32-wide kernel with the de_location channels as one K step (wd16) against the same kernel
+    with the zero-padded chunk through the 9 ring taps; above 208 vertices dance_gather_head16w is
+    that call."""
+    cfg, sd, _ = dance_state_dict(80, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer0."), device)
+    nhwc, att, loc, idx = _inputs(device, v, n=11)
+    n = loc.shape[0]
+    for terms in (3, 1):
+        a, _ = _run("dance_gather_head16", net.struct16, nhwc, att, loc, idx, n, v, ops.PAD_REFLECTION,
+                    ops.DELOC["derange"], terms, wd32=True)
+        b, _ = _run("dance_gather_head16", net.struct16, nhwc, att, loc, idx, n, v, ops.PAD_REFLECTION,
+                    ops.DELOC["derange"], terms)
+        tol = 1e-5 if terms == 3 else 5e-3
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), (v, terms)
+        if v > 208:
+            c, _ = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, n, v, ops.PAD_REFLECTION,
+                        ops.DELOC["derange"], terms)
+            assert torch.equal(a, c)

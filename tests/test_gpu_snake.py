@@ -375,7 +375,7 @@ def test_head_stack_equals_separate_launches(device, v):
             check(lib().dance_head_stack16(ctypes.byref(s16), ptr(nhwc), ptr(att), ptr(loc), ptr(idx), ptr(a),
                                            a.stride(0), slot, ptr(att_a), n, v, b, hf, wf, ops.PAD_REFLECTION,
                                            ops.DELOC["derange"], terms, st), "head_stack16")
-            check(lib().dance_gather_head16(ptr(nhwc), ptr(att), ptr(loc), ptr(idx), s16.head_w, s16.head_bs,
+            check(lib().dance_gather_head16(ptr(nhwc), ptr(att), ptr(loc), ptr(idx), s16.head_w, None, s16.head_bs,
                                             s16.head_winv, s16.head_scale, s16.head_shift, ptr(bb), bb.stride(0),
                                             ptr(att_b), n, v, b, hf, wf, 256, ops.PAD_REFLECTION,
                                             ops.DELOC["derange"], terms, st), "gather_head16")
