@@ -1450,9 +1450,13 @@ extern "C" int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stri
     return launch_check(__func__);
 }
 
-extern "C" int dance_fuse16_parts(int v)
+extern "C" int dance_fuse16_parts(int n, int v)
 {
-    return v > 128 ? 2 : 1;
+    // few contours (the reference's one-image inference: ~100 instances on 256 CUs): rings of
+    // 97..128 vertices as two parts of 64 as well, so that every contour keeps two CUs busy.
+    // DANCE_FUSE16_SMALL_N = largest such n (default 128, 0 = never).
+    static const int small_n = env_int("DANCE_FUSE16_SMALL_N", 128);
+    return v > 128 || (v > 96 && n <= small_n) ? 2 : 1;
 }
 
 extern "C" int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
@@ -1471,7 +1475,7 @@ extern "C" int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_
     a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
     a.gpart = gpart;
     // 32-wide vertex tiles; rings above 128 vertices as two parts of rta and rtb tiles
-    const int tiles = dance::ceil_div(v, 32), parts = dance_fuse16_parts(v);
+    const int tiles = dance::ceil_div(v, 32), parts = dance_fuse16_parts(n, v);
     const int rta = parts == 1 ? (tiles < 2 ? 2 : tiles) : (tiles + 1) / 2, rtb = parts == 1 ? rta : tiles - rta;
     a.part_v = parts == 1 ? v : rta * 32;
     // DANCE_FUSE16_WAVES=4 (read per call: the tests run both): two 4-wave workgroups per contour part

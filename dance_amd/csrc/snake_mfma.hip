@@ -674,7 +674,7 @@ int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, bool h
     // update).  DANCE_TAIL16=0 restores the earlier sequence.
     static const int use_tail = getenv("DANCE_TAIL16") ? atoi(getenv("DANCE_TAIL16")) : 1;
     if (use_tail) {
-        const int parts = dance_fuse16_parts(v);
+        const int parts = dance_fuse16_parts(n, v);
         float *gpart = w.gmax;                  // (n, parts <= 2, 256): gmax and h are adjacent pieces
         DANCE_REQUIRE(w.h == w.gmax + (long long)n * 256);
         DANCE_TRY(dance_fuse16_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,

@@ -429,11 +429,12 @@ int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stride, const v
 
 /* The raw form of dance_fuse16 for any ring up to 256 vertices: the same 512-output GEMM, but the
  * kernel stops before the row constant.  Both convolutions are pointwise over the ring, so rings
- * above 128 vertices are split into dance_fuse16_parts(v) parts, one workgroup each.  Outputs:
+ * above 128 vertices are split into dance_fuse16_parts(n, v) parts (2 above 128 vertices, and for at most 128 contours of
+ * 97..128 vertices: one image's instances then keep two CUs each busy), one workgroup each.  Outputs:
  * gpart (n, parts, 256) f32 = max of the fusion output over each part's vertices, and y16 (2-slot
  * P16) = the 1024 state columns of prediction[0] applied to the state, WITHOUT bias / row constant
  * / ReLU.  dance_tail16 takes both.  reference: _SnakeNet.forward snake_head.py:269-278. */
-int dance_fuse16_parts(int v);
+int dance_fuse16_parts(int n, int v);
 int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
                      const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
                      int64_t y_slot_stride, float *gpart, int n, int v, int mfma_terms, void *stream);

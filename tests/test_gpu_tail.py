@@ -43,7 +43,7 @@ def _separate(s16, state, loc, whs, att, n, v, terms, clip):
 def _fused(s16, state, loc, whs, att, n, v, terms, clip):
     dev = state.device
     slot = 256 * v
-    parts = lib().dance_fuse16_parts(v)
+    parts = lib().dance_fuse16_parts(n, v)
     gpart = torch.empty((n, parts, 256), device=dev)
     p1 = torch.zeros((n, 2, 2, 16, v, 8), dtype=torch.float16, device=dev)
     out = torch.empty((n, v, 2), device=dev)
