@@ -36,10 +36,11 @@ struct Head16Args {
     int v;
 };
 
-template <int RTG, int CT, int TERMS>
-__global__ __launch_bounds__(256, 2) void k_gather_head16w(Head16Args a)
+// MINB: workgroups per CU the register budget is cut for (3: 168 VGPRs, two B buffers instead of four)
+template <int RTG, int CT, int TERMS, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
 {
-    constexpr int NST = 2, AD = 2, NB = (NST * CT) % 4 == 0 && CT >= 3 ? 4 : 2;
+    constexpr int NST = 2, AD = 2, NB = (NST * CT) % 4 == 0 && CT >= 3 && MINB == 2 ? 4 : 2;
     static_assert(CT * 16 <= RTG * 32, "the column tiles fit the image");
     using G = Geo<RTG, 8>;
     using GD = Geo<RTG, 4>;
@@ -211,6 +212,25 @@ template <int RTG, int CT>
 int launch_head(const Head16Args &a, int n, int terms, size_t lds, hipStream_t s)
 {
     int rc;
+    if constexpr (RTG == 4) {
+        // 65..128 vertices: 38.5 KB of LDS per workgroup, so three fit a CU when the kernel is held to
+        // 168 VGPRs (a few spilled outside the MFMA loop): a third workgroup's gather phases fill the
+        // other two's barrier waits.  Same box, alternating: head 0.356 -> 0.335 ms at 1600 x 128
+        // (cfg2 256.6k -> 258.9k contours/s).  DANCE_HEAD_WGS=2 restores two per CU.
+        static const char *e = getenv("DANCE_HEAD_WGS");
+        if (!(e && atoi(e) == 2)) {
+            if (terms == 1) {
+                if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 1, 3>, lds, "dance_gather_head16w")))
+                    return rc;
+                hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 1, 3>), dim3(n), dim3(256), lds, s, a);
+            } else {
+                if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 3, 3>, lds, "dance_gather_head16w")))
+                    return rc;
+                hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 3, 3>), dim3(n), dim3(256), lds, s, a);
+            }
+            return launch_check("dance_gather_head16w");
+        }
+    }
     if (terms == 1) {
         if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 1>, lds, "dance_gather_head16w")))
             return rc;
