@@ -107,3 +107,26 @@ def test_head16_de_location_k_step_equals_padded_chunk(device, v):
             c, _ = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, n, v, ops.PAD_REFLECTION,
                         ops.DELOC["derange"], terms)
             assert torch.equal(a, c)
+
+
+def test_head16w_argument_checks(device):
+    """Channel counts that are not a multiple of 64, rings outside 16..256 and a missing de_location
+    K-step tensor are refused before any launch; n = 0 is a no-op."""
+    cfg, sd, _ = dance_state_dict(81, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer0."), device)
+    s16 = net.struct16
+    nhwc, att, loc, idx = _inputs(device, 128, n=5)
+    y = torch.zeros((5, 8, 2, 16, 128, 8), dtype=torch.float16, device=device)
+
+    def call(n, v, c, wd, deloc):
+        with torch.cuda.device(device):
+            return lib().dance_gather_head16w(ptr(nhwc), ptr(att), ptr(loc), ptr(idx), s16.head_w, wd, s16.head_bs,
+                                              s16.head_winv, s16.head_scale, s16.head_shift, ptr(y), y.stride(0),
+                                              None, n, v, 2, 40, 56, c, ops.PAD_ZEROS, deloc, 3, current_stream())
+
+    assert call(0, 128, 256, s16.head_wd, ops.DELOC["demin"]) == 0
+    for bad in [(5, 128, 96, s16.head_wd, ops.DELOC["demin"]), (5, 8, 256, s16.head_wd, ops.DELOC["demin"]),
+                (5, 260, 256, s16.head_wd, ops.DELOC["demin"]), (5, 128, 256, None, ops.DELOC["demin"])]:
+        assert call(*bad) != 0
+    assert call(5, 128, 256, None, ops.DELOC[None]) == 0          # no de_location: no K-step tensor needed
+    torch.cuda.synchronize()

@@ -110,3 +110,27 @@ def test_one_launch_init_image_index_out_of_range(device):
     got = head.init_contours(d, feat, rings, idx, one_launch=True)
     want = head.init_contours(d, feat, rings, idx, one_launch=False)
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_init_evolve_rejects_unsupported_shapes_and_accepts_empty(device):
+    """dance_snake_init16: rings above 64 vertices / other channel counts are refused by the wrapper
+    (the module then takes the separate launches); an empty batch returns an empty result."""
+    head, d = _head(device, 15)
+    feat = torch.randn((1, 16, 16, 256)).to(device)
+    assert not d.supports_init_evolve(256, 68) and not d.supports_init_evolve(128, 40)
+    assert not d.supports_init_evolve(256, 42) and d.supports_init_evolve(256, 40)
+    rings = _rings(3, 128, (64, 64), device, 2)
+    idx = torch.zeros(3, dtype=torch.int32, device=device)
+    with pytest.raises(RuntimeError):
+        d.init_evolve(0, feat, rings, idx, head._fuse16)
+    empty = d.init_evolve(0, feat, rings[:0, :40].contiguous(), idx[:0], head._fuse16)
+    assert empty.shape == (0, 40, 2)
+    # the C entry itself refuses what the wrapper filters (no launch happens)
+    from dance_amd._lib import check, current_stream, lib, ptr
+    import ctypes
+    ws = torch.empty(lib().dance_snake_workspace_bytes(3, 128), dtype=torch.uint8, device=device)
+    out = torch.empty((3, 128, 2), device=device)
+    with torch.cuda.device(device), pytest.raises(RuntimeError):
+        check(lib().dance_snake_init16(ctypes.byref(d.nets[0].struct16), ctypes.byref(head._fuse16), ptr(feat),
+                                       ptr(rings), ptr(idx), ptr(out), ptr(ws), ws.numel(), 3, 128, 1, 16, 16,
+                                       ops.PAD_ZEROS, ops.DELOC["demin"], 3, None, current_stream()), "init16")
