@@ -592,6 +592,61 @@ def gen_targets(sh):
     _save("g12_targets", **out)
 
 
+class _RingPolygon:
+    """Stand-in for shapely.geometry.Polygon as compute_targets_for_polys uses it (only
+    `.exterior.is_ccw`, snake_head.py:1101-1125): Shapely is absent, the orientation predicate is
+    oracle/targets_ref.ring_is_ccw (parity of that predicate unpinned, see there)."""
+
+    def __init__(self, pts):
+        self.exterior = NS(is_ccw=targets_ref.ring_is_ccw(pts))
+
+
+def gen_targets_driver(sh):
+    """RefineNet.compute_targets_for_polys itself (snake_head.py:982-1254), the shipped INITIAL = "box"
+    + NEW_MATCHING configuration, run from the reference's own code on two images of seeded
+    polygons plus one image without ground truth: a counter-clockwise polygon (reversed by the
+    reference), a fragmented instance (skipped), a zero-area one (skipped)."""
+    fu = ref_loader.load_fcose_utils()
+    sh.get_aux_extreme_points = fu.get_aux_extreme_points
+    sh.get_extreme_points = fu.get_extreme_points
+    sh.Polygon = _RingPolygon
+    v = 32
+    net = sh.RefineNet(ref_loader.dance_cfg(num_sampling=v, num_convs=0, convs_dim=4))
+    assert net.initial == "box" and net.new_matching and not net.original
+    polys = target_polygons()
+    flat = np.array([[10, 10], [20, 20], [30, 30], [40, 40]], np.float32)           # zero area
+    inst = [[[polys[0].reshape(-1)], [polys[1][::-1].copy().reshape(-1)], [polys[2].reshape(-1)],
+             [polys[3].reshape(-1), polys[4].reshape(-1)]],                           # last: fragmented
+            [],
+            [[polys[5].reshape(-1)], [flat.reshape(-1)], [polys[6].reshape(-1)], [polys[7].reshape(-1)]]]
+
+    def bounds(parts):
+        c = np.concatenate([np.asarray(q).reshape(-1, 2) for q in parts])
+        return [float(c[:, 0].min()), float(c[:, 1].min()), float(c[:, 0].max()), float(c[:, 1].max())]
+
+    boxes = [torch.tensor([bounds(q) for q in im], dtype=torch.float32).reshape(-1, 4) for im in inst]
+    sizes = [(800, 1216), (800, 1216), (704, 1000)]
+    tg = [NS(gt_boxes=NS(tensor=b.clone()), gt_masks=NS(polygons=im)) for b, im in zip(boxes, inst)]
+    want = net.compute_targets_for_polys(tg, sizes)
+    got = targets_ref.compute_targets_for_polys_box(inst, boxes, sizes, v)
+    out = {"v": np.int64(v), "n_images": np.int64(len(inst))}
+    assert sorted(want) == sorted(got)
+    for k in want:
+        a, b = want[k], got[k]
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), k
+        out["out_" + k] = a.numpy()
+    assert want["sample_locs"].shape == (6, v, 2) and want["image_idx"].tolist() == [0, 0, 0, 2, 2, 2]
+    for i, im in enumerate(inst):
+        out["boxes%d" % i] = boxes[i].numpy()
+        out["n_inst%d" % i] = np.int64(len(im))
+        for j, parts in enumerate(im):
+            out["n_parts%d_%d" % (i, j)] = np.int64(len(parts))
+            for k, q in enumerate(parts):
+                out["poly%d_%d_%d" % (i, j, k)] = np.asarray(q, np.float32)
+    out["sizes"] = np.array(sizes, np.int64)
+    _save("g13_targets_driver", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -603,7 +658,7 @@ def main():
              "dance": lambda: gen_dance(sh), "dsnake": lambda: gen_dsnake(dh),
              "upsample2x": lambda: gen_upsample2x(sh), "bottom_out": lambda: gen_bottom_out(sh),
              "attender": gen_attender, "edge_head": gen_edge_head, "fcose": gen_fcose,
-             "targets": lambda: gen_targets(sh)}
+             "targets": lambda: gen_targets(sh), "targets_driver": lambda: gen_targets_driver(sh)}
     # `python -m oracle.gen_golden attender ...` regenerates only the named fixtures (floating-
     # point fixtures move in the last bits with the host CPU's kernels: keep the committed ones)
     for name in (sys.argv[1:] or list(steps)):

@@ -353,3 +353,78 @@ def single_uniform_multisegment_matching(dense, sampled, ext_idx, up_rate, num_s
         if len(out) == v:
             return out, 0
     return reorder_perloss(dense[::up_rate], sampled)[0], 1
+
+
+# --------------------------------------------------------------------------- the driver
+def ring_is_ccw(cnt):
+    """`Polygon(cnt).exterior.is_ccw` as the reference calls it (snake_head.py:1101-1125).
+    Shapely (1.7.1 pinned, requirements.txt:1) is NOT under /root/reference and not importable
+    here: this restates its published shapely/algorithms/cga.py -- signed_area(ring) =
+    sum_i x_i * (y_{i+1} - y_{i-1}) / 2 over the CLOSED ring as a sequential Python float sum,
+    is_ccw = signed_area >= 0.  PARITY OF THIS PREDICATE IS UNPINNED (no fixture can exist here);
+    for polygons of non-zero area every formulation of the orientation agrees."""
+    pts = [(float(x), float(y)) for x, y in np.asarray(cnt).reshape(-1, 2)]
+    if pts[0] != pts[-1]:
+        pts.append(pts[0])
+    xs = [q[0] for q in pts]
+    ys = [q[1] for q in pts]
+    xs.append(xs[1])
+    ys.append(ys[1])
+    return sum(xs[i] * (ys[i + 1] - ys[i - 1]) for i in range(1, len(pts))) / 2.0 >= 0.0
+
+
+def compute_targets_for_polys_box(polygons_per_image, boxes_per_image, image_sizes, num_sampling, up_rate=5):
+    """RefineNet.compute_targets_for_polys (snake_head.py:982-1254) for the shipped configuration:
+    INITIAL = "box", ORIGINAL off, NEW_MATCHING on (up_rate 5, :997-1000), REORDER_METHOD != "curvegcn",
+    JITTERING 0.  polygons_per_image[i][j] = the instance's list of flat (2 P) arrays
+    (detectron2 PolygonMasks.polygons, :967-980), boxes_per_image[i] (n_i, 4) float32 xyxy tensor,
+    image_sizes[i] = (h, w).  Returns the reference's dict (torch CPU tensors)."""
+    import torch
+
+    from . import snake_ref
+    locs, tars, dense_t, image_index, scales, whs, init_locs, init_tars = [], [], [], [], [], [], [], []
+    for im_i, (polys_im, bboxes) in enumerate(zip(polygons_per_image, boxes_per_image)):
+        if bboxes.numel() == 0:                                                  # :1011
+            continue
+        h_img, w_img = image_sizes[im_i]
+        ws = bboxes[:, 2] - bboxes[:, 0]
+        hs = bboxes[:, 3] - bboxes[:, 1]
+        box = snake_ref.box_polygon(bboxes)                                      # :1074-1077
+        octagons = snake_ref.uniform_upsample(box[None], num_sampling)[0]        # :1078-1080
+        init_box = snake_ref.uniform_upsample(box[None], 40)[0]                  # :1083
+        ex_pts = init_box                                                        # :1084
+        for j, polys in enumerate(polys_im):
+            contour = [np.array(x).reshape(-1, 2).astype(np.float32) for x in polys]   # :973-975
+            if len(contour) > 1:                                                 # fragmented, :976-977
+                continue
+            cnt = contour[0]
+            oct_t, in_box, ex_tar, w, h = octagons[j], init_box[j], ex_pts[j], ws[j], hs[j]
+            scale = torch.min(w, h)
+            cnt = cnt[::-1] if ring_is_ccw(cnt) else cnt                         # :1101
+            if ring_is_ccw(cnt):                                                 # :1105-1106
+                continue
+            oct_pts = oct_t.numpy()
+            assert not ring_is_ccw(oct_pts), "1) contour must be clock-wise!"    # :1118-1120
+            assert not ring_is_ccw(in_box.numpy()), "0) init box must be clock-wise!"
+            big = uniform_sample(cnt, len(cnt) * num_sampling * up_rate)         # :1134-1136
+            tt = int(np.argmin(np.power(big - oct_pts[0], 2).sum(axis=1)))       # :1139-1141
+            dense = np.roll(big, -tt, axis=0)[::len(cnt)]                        # :1142-1144
+            dense, ext = get_aux_extreme_points(dense)                           # :1147-1149
+            oct_pts = roll_to_first_target(oct_pts, dense)                       # :1150-1155
+            oct_t = torch.from_numpy(oct_pts)                                    # :1156
+            matched, _status = single_uniform_multisegment_matching(dense, oct_pts, ext, up_rate, num_sampling)
+            matched = torch.tensor(matched).float()                              # :1160-1162
+            matched[..., 0].clamp_(min=0, max=w_img - 1)                         # :1172-1173
+            matched[..., 1].clamp_(min=0, max=h_img - 1)
+            locs.append(oct_t)
+            dense_t.append(matched)                                              # :1175: the SAME tensor
+            tars.append(matched)
+            image_index.append(im_i)
+            scales.append(scale)
+            whs.append([w, h])
+            init_locs.append(in_box)
+            init_tars.append(ex_tar)
+    return {"sample_locs": torch.stack(locs, 0), "sample_targets": torch.stack(tars, 0),
+            "sample_dense_targets": torch.stack(dense_t, 0), "scales": torch.stack(scales, 0),
+            "whs": torch.tensor(whs), "image_idx": torch.tensor(image_index),
+            "init_locs": torch.stack(init_locs, 0), "init_targets": torch.stack(init_tars, 0)}

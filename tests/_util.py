@@ -164,3 +164,21 @@ def edge_head_inputs(seed, hf=48, wf=64, n=6):
                                                      cell=max(2, 8 // k))
     boxes = synthetic.make_boxes(n, hf * 4, wf * 4, seed + 9, r_min=10, r_max=50)
     return feats, boxes
+
+
+def targets_driver_fixture():
+    """Inputs and expected outputs of tests/golden/g13_targets_driver.npz (the reference's own
+    RefineNet.compute_targets_for_polys on three images): (polygons_per_image, boxes_per_image,
+    image_sizes, num_sampling, expected dict of torch tensors)."""
+    g = golden("g13_targets_driver")
+    n_images = int(g["n_images"])
+    polys, boxes = [], []
+    for i in range(n_images):
+        im = []
+        for j in range(int(g["n_inst%d" % i])):
+            im.append([g["poly%d_%d_%d" % (i, j, k)].numpy() for k in range(int(g["n_parts%d_%d" % (i, j)]))])
+        polys.append(im)
+        boxes.append(g["boxes%d" % i].reshape(-1, 4))
+    sizes = [tuple(int(x) for x in row) for row in g["sizes"].tolist()]
+    want = {k[4:]: t for k, t in g.items() if k.startswith("out_")}
+    return polys, boxes, sizes, int(g["v"]), want

@@ -137,3 +137,45 @@ def test_uniform_sample_random_vs_oracle(device):
     for c, k, a in zip(polys, newp, got):
         w = targets_ref.uniform_sample(c, k)
         assert a.cpu().numpy().dtype == w.dtype and np.array_equal(a.cpu().numpy(), w)
+
+
+def test_compute_targets_for_polys_golden(device):
+    """dance_amd.targets.compute_targets_for_polys against the reference's own driver (g13): three
+    images, a reversed ring, a fragmented and a zero-area instance, an image without ground truth."""
+    from _util import targets_driver_fixture
+    polys, boxes, sizes, v, want = targets_driver_fixture()
+    got = targets.compute_targets_for_polys(polys, boxes, sizes, v, device=device)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        a = got[k].cpu()
+        assert a.dtype == want[k].dtype and a.shape == want[k].shape, k
+        assert torch.equal(a, want[k]), k
+
+
+def test_compute_targets_for_polys_vs_oracle_random(device):
+    """200 random star polygons over 8 images at the shipped 128 x 5 sampling, some given
+    counter-clockwise, against the CPU oracle; plus the error paths."""
+    rng = np.random.default_rng(3)
+    polys, boxes, sizes = [], [], []
+    for i in range(8):
+        im, bx = [], []
+        for j in range(25):
+            c = _star(100 * i + j, int(rng.integers(6, 120)), 300 + 20 * j, 250 + 10 * i, int(rng.integers(15, 140)))
+            if j % 4 == 0:
+                c = c[::-1].copy()
+            im.append([c.reshape(-1)])
+            bx.append([float(c[:, 0].min()), float(c[:, 1].min()), float(c[:, 0].max()), float(c[:, 1].max())])
+        polys.append(im)
+        boxes.append(torch.tensor(bx, dtype=torch.float32))
+        sizes.append((640, 900))
+    v = 128
+    got = targets.compute_targets_for_polys(polys, boxes, sizes, v, device=device)
+    want = targets_ref.compute_targets_for_polys_box(polys, boxes, sizes, v)
+    for k in want:
+        assert torch.equal(got[k].cpu(), want[k]), k
+    assert got["sample_locs"].shape == (200, v, 2)
+    assert float(got["sample_targets"][..., 0].max()) <= 899.0 and float(got["sample_targets"][..., 1].max()) <= 639.0
+    with pytest.raises(RuntimeError):                   # nothing left: the reference's torch.stack([]) fails too
+        targets.compute_targets_for_polys([[]], [torch.zeros((0, 4))], [(10, 10)], v, device=device)
+    with pytest.raises(RuntimeError):
+        targets.compute_targets_for_polys([polys[0]], [boxes[0][:3]], [sizes[0]], v, device=device)
