@@ -305,11 +305,13 @@ class RefineNet(_SnakeHeadBase):
         """The `snake_deformation` scope (snake_head.py:1822-1862): per-iteration contours."""
         with timer.env("snake_feat_prep"):
             d, nhwc, att = self._features(features)
-        # DANCE_STREAMS=2: halves of the contours on two HIP streams (bit-identical, ~8 % faster
-        # on large batches; ContourDeformer.deform)
+        # halves of the contours on two HIP streams (bit-identical results; one half's kernel tails and
+        # launch gaps overlap the other half's kernels: +3..4 % at 1600+ contours) from 1024 contours
+        # on, never under stream capture; DANCE_STREAMS=<k> fixes the count
+        env = os.environ.get("DANCE_STREAMS")
+        streams = int(env) if env else (2 if len(locations) >= 1024 and not torch.cuda.is_current_stream_capturing() else 1)
         with timer.env("snake_deformation"):
-            return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc",
-                            streams=int(os.environ.get("DANCE_STREAMS", "1")))
+            return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc", streams=streams)
 
     def single_test(self, features, pred_instances):
         """snake_head.py:1763-1869 (one image)."""
