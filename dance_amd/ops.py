@@ -29,14 +29,16 @@ def _f32c(t):
 
 
 # --------------------------------------------------------------------------- resampler
-def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True):
+def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True, deferred=None):
     """Fused RefineNet.uniform_upsample (snake_head.py:764-794).
 
     kind RAW:     poly (N,E,2) [or the reference's (1,N,E,2)] polygon vertices
     kind BOX/QUAD: poly (N,4) xyxy boxes;  kind OCTAGON: poly (N,4,2) extreme points
     Returns (points (N,p_num,2) f32, edge_start_idx (N,E) i64).  With `check_status` the
     reference's `assert torch.all(edge_num_sum == p_num)` (snake_head.py:782) is kept,
-    which -- like the reference -- synchronises with the device.
+    which -- like the reference -- synchronises with the device.  `deferred`: a list; the status
+    tensor is appended to it instead and the caller runs `check_upsample_status` on the list later
+    (one synchronisation for a whole chain of asynchronous launches).
     """
     _need_gpu(poly)
     if kind == POLY_RAW and poly.dim() == 4:
@@ -62,9 +64,18 @@ def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True):
         check(lib().dance_uniform_upsample(kind, ptr(poly), n, e, int(p_num), ptr(out), ptr(start),
                                            ptr(status), current_stream()), "uniform_upsample")
     # (under HIP-graph capture the check, a host synchronisation, is skipped: dance_amd/graph.py)
-    if check_status and n and not torch.cuda.is_current_stream_capturing():
+    if deferred is not None:
+        deferred.append(status)
+    elif check_status and n and not torch.cuda.is_current_stream_capturing():
         assert not bool(status.any()), "uniform_upsample: edge counts do not sum to p_num"
     return out, start
+
+
+def check_upsample_status(deferred):
+    """The assert of `uniform_upsample` for status tensors collected with `deferred=`."""
+    if deferred and not torch.cuda.is_current_stream_capturing():
+        bad = torch.stack([s.any() for s in deferred if s.numel()] or [torch.zeros((), dtype=torch.bool)])
+        assert not bool(bad.any()), "uniform_upsample: edge counts do not sum to p_num"
 
 
 # ------------------------------------------------------------------------------ layout

@@ -125,3 +125,30 @@ def test_config5_large_sweep_256v(device):
         for it in range(3):
             assert torch.equal(alone[it], preds[it][sl]), (img, it)
     _check_sample(d, preds, sd, feats, init, idx, whs, [7, 40000, 76799])
+
+
+def test_dsnake_two_streams_equal_one_stream(device, monkeypatch):
+    """Dsnake at 32 x 100 with the batch's halves on two HIP streams (DANCE_STREAMS=2) against one
+    stream, three times over: every stage bit-identical.  With two streams
+    kernels of different kinds share CUs -- the resampler beside the snake's MFMA kernels is where a
+    packed-fp32 lerp once came out wrong in lanes 48..63 (dance_amd/build.py, NOPK)."""
+    b, per = 32, 100
+    cfg, sd, _ = dsnake_state_dict(4321)
+    head = modules.DsnakeHead(cfg)
+    head.load_state_dict(sd)
+    head = head.to(device).eval()
+    feats = _features(b, 256, 901, device, attention=False)
+    boxes = synthetic.make_boxes(b * per, HF * 4, WF * 4, 80).view(b, per, 4)
+
+    def run(streams):
+        monkeypatch.setenv("DANCE_STREAMS", str(streams))
+        insts = [FakeInstances((HF * 4, WF * 4), pred_boxes=FakeBoxes(boxes[i].to(device))) for i in range(b)]
+        with torch.no_grad():
+            head(feats, insts, None)
+        st = head.last_stages
+        return [st["exts_raw"].clone(), st["exts"].clone(), st["octagons"].clone()] + [p.clone() for p in st["preds"]]
+
+    ref = run(1)
+    for _ in range(3):
+        for a, r in zip(run(2), ref):
+            assert torch.equal(a, r)
