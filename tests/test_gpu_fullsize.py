@@ -75,6 +75,12 @@ def test_config3_dance_32x100_attention(device):
     for it in range(3):
         assert torch.equal(preds[it], again[it])
         assert torch.equal(preds[it][perm], shuffled[it])
+    # two HIP streams (the RefineNet module's default from 1024 contours on): kernels of the two halves
+    # share CUs; three runs, every iteration bit-identical to the one-stream result
+    for _ in range(3):
+        two = d.deform(feats, init, idx.to(device), [(HF * 4, WF * 4)] * b, whs.to(device), streams=2)
+        for it in range(3):
+            assert torch.equal(preds[it], two[it])
     _check_sample(d, preds, sd, feats, init, idx, whs, [0, 1234, 3199])
 
 
