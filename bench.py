@@ -764,7 +764,7 @@ def main():
             "whole_path_algorithmic_TFLOPs": total_flops / (ms_per_step * 1e-3) / 1e12,
             "stage_ms": dict(stage_avg, layout_nchw_to_nhwc=layout_ms,
                              note="HIP events on the launch stream (14 boundaries per iteration).  Fast mode: "
-                                  "`fusion_max` is k_fuse16r (fusion + ring max + prediction[0]'s state part), "
+                                  "`fusion_max` is k_fuse16w (fusion + ring max + prediction[0]'s state part, 16-wide tiles), "
                                   "`offset_update` is k_tail16 (row constant, ReLU, prediction[2], prediction[4], "
                                   "offset update); row_constant / pred0 / pred1 are inside those two launches"),
             "streams": args.streams,

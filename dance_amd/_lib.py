@@ -121,6 +121,9 @@ SIGNATURES = {
     "dance_fuse16_parts": (c_int, [c_int, c_int]),
     "dance_fuse16_raw": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int,
                                  c_int, P]),
+    "dance_fuse16w_supported": (c_int, [c_int, c_int]),
+    "dance_fuse16w_raw": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int, c_int,
+                                  c_int, P]),
     "dance_tail16": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int,
                              c_int, c_int, c_float, c_float, c_int, P]),
     "dance_gather_head16": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,

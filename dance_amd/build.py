@@ -40,6 +40,7 @@ SOURCES = [
     ("tail16.hip", []),
     ("init16.hip", []),
     ("head16.hip", []),
+    ("fuse16w.hip", []),
     ("featprep16.hip", []),
     ("raster.hip", ["-ffp-contract=off"]),
     ("attender.hip", []),

@@ -282,6 +282,90 @@ __device__ __forceinline__ void mfma16_core_sw(f32x4 (&acc)[2][CTW], const char 
 #undef DANCE_LOAD_B
 }
 
+// Staging of the next chunk image: this wave's rows (wave, wave + NW, ...), lanes along the
+// row; lanes past the ring length repeat the last vertex (same value to the same address),
+// which keeps loads and stores branch-free and the staging array in registers.
+template <int RT, int CBC, int NW>
+struct StageGeo {
+    using G = Geo<RT, CBC>;
+    static constexpr int RPW = (2 * CBC) / NW;      // rows per wave
+    static constexpr int N = RPW * G::CPR;          // 16-B loads per lane
+    static_assert((2 * CBC) % NW == 0, "rows split evenly over the waves");
+};
+
+// src: uniform byte pointer to (plane 0, chunk's first block) of the P16 slot
+// vs: vertices per row of the P16 slot in memory (the ring length); v: vertices staged (a part
+// of the ring when the caller splits it, src then points at the part's first vertex)
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_load(u32x4 (&reg)[(StageGeo<RT, CBC, NW>::N)], int jlo, int jhi,
+                                           const char *src, int v, int wave, int lane, int vs)
+{
+    using S = StageGeo<RT, CBC, NW>;
+#pragma unroll
+    for (int j = 0; j < S::N; ++j)
+        if (j >= jlo && j < jhi) {
+            const int row = wave + NW * (j / S::G::CPR);
+            const int plane = row >= CBC ? 1 : 0, cbl = row - plane * CBC;
+            const unsigned col = min((j % S::G::CPR) * 64 + lane, v - 1);
+            reg[j] = *reinterpret_cast<const u32x4 *>(src + (plane * 256ll + cbl * 16ll) * vs + col * 16u);
+        }
+}
+
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_load(u32x4 (&reg)[(StageGeo<RT, CBC, NW>::N)], int jlo, int jhi,
+                                           const char *src, int v, int wave, int lane)
+{
+    stage_load<RT, CBC, NW>(reg, jlo, jhi, src, v, wave, lane, v);
+}
+
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_commit(const u32x4 (&reg)[(StageGeo<RT, CBC, NW>::N)], char *xs,
+                                             unsigned lds0, int v, int wave, int lane)
+{
+    using S = StageGeo<RT, CBC, NW>;
+#pragma unroll
+    for (int j = 0; j < S::N; ++j) {
+        const int row = wave + NW * (j / S::G::CPR);
+        const unsigned col = min((j % S::G::CPR) * 64 + lane, v - 1);
+        *reinterpret_cast<u32x4 *>(xs + lds0 + (row * S::G::VP + col) * 16u) = reg[j];
+    }
+}
+
+// The same staging without registers: global_load_lds_dwordx4 moves 16 B per lane straight into
+// LDS (destination = M0 base + lane * 16: a wave-instruction fills 64 consecutive words of an
+// image row).  Written as inline asm on purpose: through the builtin the compiler cannot tell the
+// image being filled from the one being read and puts s_waitcnt vmcnt(0) in front of the MFMA
+// loop's ds_reads, which also drains the weight prefetch (measured: slower than registers).  The
+// asm is invisible to its counter bookkeeping -- its own waits for the weight loads stay correct
+// (vmcnt retires in order, they only ever wait for more) -- so the CALLER must issue
+// s_waitcnt vmcnt(0) before the barrier that publishes the image (stage_dma_wait).
+//   lds_dst: byte offset of the image inside the workgroup's LDS (wave-uniform)
+template <int RT, int CBC, int NW>
+__device__ __forceinline__ void stage_dma(int jlo, int jhi, const char *src, unsigned lds_dst, int v, int wave,
+                                          int lane, int vs)
+{
+    using S = StageGeo<RT, CBC, NW>;
+#pragma unroll
+    for (int j = 0; j < S::N; ++j)
+        if (j >= jlo && j < jhi) {
+            const int row = wave + NW * (j / S::G::CPR);
+            const int plane = row >= CBC ? 1 : 0, cbl = row - plane * CBC;
+            const int col0 = (j % S::G::CPR) * 64;
+            const unsigned col = min(col0 + lane, v - 1);
+            const char *g = src + (plane * 256ll + cbl * 16ll) * vs + col * 16u;
+            const unsigned l = __builtin_amdgcn_readfirstlane(lds_dst + (unsigned)(row * S::G::VP + col0) * 16u);
+            // an odd number of 32-wide tiles: the last pass covers half a row, the other lanes
+            // would land in the next row
+            if (RT % 2 == 0 || col0 + lane < RT * 32)
+                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(l) : "memory");
+        }
+}
+
+__device__ __forceinline__ void stage_dma_wait()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int RT, int OTW>
 __device__ __forceinline__ void init_acc16(f32x16 (&acc)[OTW][RT], const float *bias_s, int o0, int h, float mul)
 {

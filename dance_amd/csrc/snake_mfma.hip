@@ -677,8 +677,14 @@ int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, bool h
         const int parts = dance_fuse16_parts(n, v);
         float *gpart = w.gmax;                  // (n, parts <= 2, 256): gmax and h are adjacent pieces
         DANCE_REQUIRE(w.h == w.gmax + (long long)n * 256);
-        DANCE_TRY(dance_fuse16_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
-                                   pstride, slot, gpart, n, v, mfma_terms, stream));
+        // the fusion kernel on 16-wide vertex tiles (fuse16w.hip); DANCE_FUSE16_SHAPE=32: k_fuse16r
+        static const int fuse_shape = getenv("DANCE_FUSE16_SHAPE") ? atoi(getenv("DANCE_FUSE16_SHAPE")) : 16;
+        if (fuse_shape == 16 && dance_fuse16w_supported(parts, v))
+            DANCE_TRY(dance_fuse16w_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
+                                        pstride, slot, gpart, n, v, parts, mfma_terms, stream));
+        else
+            DANCE_TRY(dance_fuse16_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
+                                       pstride, slot, gpart, n, v, mfma_terms, stream));
         DANCE_TRY(mark());
         DANCE_TRY(mark());      // row constant: inside the tail kernel
         DANCE_TRY(mark());      // prediction[0]'s ReLU: inside the tail kernel

@@ -439,6 +439,19 @@ int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, con
                      const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
                      int64_t y_slot_stride, float *gpart, int n, int v, int mfma_terms, void *stream);
 
+/* dance_fuse16_raw on 16-wide vertex tiles (v_mfma_f32_16x16x32_f16; csrc/fuse16w.hip): same
+ * inputs, outputs and `parts` meaning (dance_fuse16w_supported(parts, v): one part for 16..128
+ * vertices, two for 97..256): a part runs ceil(vertices / 16) column tiles rounded up to an
+ * instantiated count -- 196 vertices as 7 + 6 tiles = 208 columns instead of 224, 40 as 3 = 48
+ * instead of 64.  Same products per output element in another summation order; the default fusion
+ * kernel of dance_snake_evolve16 (DANCE_FUSE16_SHAPE=32 restores dance_fuse16_raw).
+ * reference: _SnakeNet.forward snake_head.py:269-278. */
+int dance_fuse16w_supported(int parts, int v);
+int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
+                      const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
+                      int64_t y_slot_stride, float *gpart, int n, int v, int parts, int mfma_terms,
+                      void *stream);
+
 /* The end of a _SnakeNet and of evolve in one launch: global state = max over gpart's parts ->
  * row constant h = pred0_bias + wg^T g (as dance_row_constant) -> relu(p1 + h) -> prediction[2]
  * (w1_16: packed (2,1,32,64,8), b1_scaled, w1_inv_scale) + ReLU -> prediction[4] + offset update
