@@ -91,9 +91,11 @@ def test_fuse_raw_tail_equals_separate_launches(device, v):
 
 
 @pytest.mark.parametrize("v", [128, 196])
-def test_fuse_raw_tail_many_contours_vs_torch(device, v):
-    """1100 contours take the 4-contours-per-workgroup tail kernel; checked against torch fp32
-    evaluated from the same state (the chain of k = 1 convolutions as the reference writes it)."""
+def test_fuse_raw_tail_many_contours_vs_torch(device, v, monkeypatch):
+    """1100 contours through the 4-contours-per-workgroup tail kernel (DANCE_TAIL16_GROUP=4); checked
+    against torch fp32 evaluated from the same state (the chain of k = 1 convolutions as the
+    reference writes it)."""
+    monkeypatch.setenv("DANCE_TAIL16_GROUP", "4")
     cfg, sd, _ = dance_state_dict(32, 128)
     sub = snake.sub_state_dict(sd, "deformer2.")
     net = snake.SnakeNetWeights(sub, device)
@@ -115,14 +117,18 @@ def test_fuse_raw_tail_many_contours_vs_torch(device, v):
     assert float((out - want).abs().max()) <= 1e-4 * float(want.abs().max())
 
 
-def test_tail16_group_sizes_agree(device):
-    """Contours 4 per workgroup (n >= 1024) and one per workgroup give the same bits: the row
-    constant's summation order does not depend on the grouping."""
+def test_tail16_group_sizes_agree(device, monkeypatch):
+    """Contours 4 per workgroup (DANCE_TAIL16_GROUP=4) and one per workgroup (the default) give the
+    same bits: the row constant's summation order does not depend on the grouping."""
     cfg, sd, _ = dance_state_dict(33, 128)
     net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer0."), device)
     v, n = 100, 1027                                        # 1027 = 256 groups of 4 + 3
     x, state, loc, whs, att = _inputs(n, v, device, 5)
+    monkeypatch.setenv("DANCE_TAIL16_GROUP", "4")
     _, big = _fused(net.struct16, state, loc, whs, att, n, v, 3, False)
+    monkeypatch.delenv("DANCE_TAIL16_GROUP")
+    _, one = _fused(net.struct16, state, loc, whs, att, n, v, 3, False)
+    assert torch.equal(big, one)
     k = 300
     _, small = _fused(net.struct16, state[-k:].contiguous(), loc[-k:].contiguous(), whs[-k:].contiguous(),
                       att[-k:].contiguous(), k, v, 3, False)
