@@ -477,8 +477,9 @@ int dance_gather_head16(const float *feat, const float *att, const float *loc,
 /* dance_gather_head16 on 16-wide vertex tiles (v_mfma_f32_16x16x32_f16): the ring is padded to a
  * multiple of 16 columns instead of 32 (196 vertices: 208 instead of 224), and the two de_location
  * channels are one K step (wd16, see dance_snake_net16.head_wd) instead of a zero-padded chunk
- * through all 9 ring taps.  Rings above DANCE_HEAD16W_MAX_V vertices are handed to
- * dance_gather_head16 with wd16 (224 / 256 columns either way).  Same results up to summation order.  reference: as dance_gather_head16
+ * through all 9 ring taps.  Rings above DANCE_HEAD16W_MAX_V vertices run as two half
+ * rings in two workgroups, each with 4 halo vertices either side (DANCE_HEAD_HALVES=0: handed to
+ * dance_gather_head16 with wd16).  Same results up to summation order.  reference: as dance_gather_head16
  * (snake_head.py:1542-1572, 1587-1610, 1639-1652, _SnakeNet.head :233). */
 #define DANCE_HEAD16W_MAX_V 208
 int dance_gather_head16w(const float *feat, const float *att, const float *loc,
