@@ -249,10 +249,12 @@ int launch_head(const Head16Args &a, int n, int terms, size_t lds, hipStream_t s
 // waves x 8 column tiles, three workgroups per CU.  LDS image columns: [0, len + 4) = vertices
 // h0 .. h0 + len + 3, the last 4 columns of the image's ring period (VC = 16 CT + 8) = vertices
 // h0 - 4 .. h0 - 1, so the core's ring walk with period VC reads the right neighbours unchanged.
-template <int CT, int TERMS>
+// Also used for 65..128 vertices when there are fewer contours than CUs (one image's ~100
+// detections): twice the workgroups, each half as long.
+template <int RTG, int CT, int TERMS>
 __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
 {
-    constexpr int RTG = 5, NST = 2, AD = 2, NB = 2, VC = 16 * CT + 8;
+    constexpr int NST = 2, AD = 2, NB = 2, VC = 16 * CT + 8;
     static_assert(VC <= RTG * 32, "the half ring and its halo fit the image");
     using G = Geo<RTG, 8>;
     using GD = Geo<RTG, 4>;
@@ -423,20 +425,23 @@ __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
     }
 }
 
+template <int RTG, int CT>
 int launch_head_halves(const Head16Args &a, int n, int terms, hipStream_t s)
 {
-    constexpr int CT = 8, VC = 16 * CT + 8;
-    const int h1 = ((a.v + 15) / 16 + 1) / 2 * 16;              // tiles split 7+7, 8+7 or 8+8
-    const size_t lds = (size_t)2 * 8 * (5 * 32 + 1) * 16 + ((size_t)8 * VC + 2 * a.v + 16) * sizeof(float);
+    constexpr int VC = 16 * CT + 8;
+    const int h1 = ((a.v + 15) / 16 + 1) / 2 * 16;              // tiles split evenly or first half one more
+    if (h1 > 16 * CT || a.v - h1 > 16 * CT || a.v - h1 < 1)
+        return dance::fail(1, "dance_gather_head16w", "ring length does not fit the half-ring kernel");
+    const size_t lds = (size_t)2 * 8 * (RTG * 32 + 1) * 16 + ((size_t)8 * VC + 2 * a.v + 16) * sizeof(float);
     int rc;
     if (terms == 1) {
-        if ((rc = dance::allow_lds((const void *)k_gather_head16h<CT, 1>, lds, "dance_gather_head16w")))
+        if ((rc = dance::allow_lds((const void *)k_gather_head16h<RTG, CT, 1>, lds, "dance_gather_head16w")))
             return rc;
-        hipLaunchKernelGGL((k_gather_head16h<CT, 1>), dim3(n, 2), dim3(256), lds, s, a, h1);
+        hipLaunchKernelGGL((k_gather_head16h<RTG, CT, 1>), dim3(n, 2), dim3(256), lds, s, a, h1);
     } else {
-        if ((rc = dance::allow_lds((const void *)k_gather_head16h<CT, 3>, lds, "dance_gather_head16w")))
+        if ((rc = dance::allow_lds((const void *)k_gather_head16h<RTG, CT, 3>, lds, "dance_gather_head16w")))
             return rc;
-        hipLaunchKernelGGL((k_gather_head16h<CT, 3>), dim3(n, 2), dim3(256), lds, s, a, h1);
+        hipLaunchKernelGGL((k_gather_head16h<RTG, CT, 3>), dim3(n, 2), dim3(256), lds, s, a, h1);
     }
     return launch_check("dance_gather_head16w");
 }
@@ -476,7 +481,14 @@ extern "C" int dance_gather_head16w(const float *feat, const float *att, const f
             return dance_gather_head16(feat, att, loc, image_idx, w16, wd16, bias_scaled, w_inv_scale, scale,
                                        shift, y16, y_stride, att_out, n, v, b, hf, wf, c, padding_mode,
                                        deloc_type, mfma_terms, stream);
-        return launch_head_halves(a, n, mfma_terms, s);
+        return launch_head_halves<5, 8>(a, n, mfma_terms, s);
+    }
+    // fewer contours than CUs (one image's detections): 65..128-vertex rings as two half rings too,
+    // twice the workgroups at half the length each (DANCE_HEAD_SMALL_N: largest such n, 0 = never)
+    if (v > 64 && v <= 128) {
+        const char *e = getenv("DANCE_HEAD_SMALL_N");
+        if (n <= (e ? atoi(e) : 128))
+            return v <= 96 ? launch_head_halves<2, 3>(a, n, mfma_terms, s) : launch_head_halves<3, 4>(a, n, mfma_terms, s);
     }
     const int rtg = v <= 64 ? 2 : (v <= 128 ? 4 : 7);
     const size_t lds = (size_t)2 * 8 * (rtg * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);

@@ -59,6 +59,25 @@ def test_head16w_equals_head16(device, v):
         assert torch.equal(att_a, att_b)
 
 
+@pytest.mark.parametrize("v", [65, 68, 80, 81, 96, 97, 100, 112, 113, 128])
+def test_head16w_small_n_half_rings(device, v, monkeypatch):
+    """65..128-vertex rings with at most DANCE_HEAD_SMALL_N (128) contours run as two half rings (the one
+    image's-detections case); test_head16w_equals_head16 above covers them too (29 contours) -- here the
+    whole-ring kernel (threshold 0) and the half-ring one are compared directly"""
+    cfg, sd, _ = dance_state_dict(82, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
+    nhwc, att, loc, idx = _inputs(device, v, n=37)
+    for terms, deloc in [(3, "derange"), (1, "demin")]:
+        monkeypatch.setenv("DANCE_HEAD_SMALL_N", "0")
+        whole, att_w = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, 37, v, ops.PAD_REFLECTION,
+                            ops.DELOC[deloc], terms)
+        monkeypatch.delenv("DANCE_HEAD_SMALL_N")
+        halves, att_h = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, 37, v, ops.PAD_REFLECTION,
+                             ops.DELOC[deloc], terms)
+        assert torch.equal(halves, whole)                       # same K order per output: bit-identical
+        assert torch.equal(att_h, att_w)
+
+
 def test_head16w_vs_torch(device):
     """torch fp32: grid_sample (reflection) -> derange de_location -> circular Conv1d k = 9 -> ReLU ->
     BatchNorm (eval), from the same weights."""
