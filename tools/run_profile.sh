@@ -7,7 +7,7 @@ OUT=/tmp/prof_$TAG
 KEEP=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT $KEEP
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $ROOT/bench.py --steps 7 --warmup 2 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/trace.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/trace.err
 timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc1 -o $TAG -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc1.json 2> $OUT/pmc1.err
 timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc2 -o $TAG -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc2.json 2> $OUT/pmc2.err
 timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc3 -o $TAG -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc3.json 2> $OUT/pmc3.err
