@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -122,6 +122,9 @@ SIGNATURES = {
     "dance_fuse16_raw": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int,
                                  c_int, P]),
     "dance_fuse16w_supported": (c_int, [c_int, c_int]),
+    "dance_fuse16w_tail_split": (c_int, [c_int, c_int]),
+    "dance_fuse16w_raw_split": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int, c_int,
+                                        c_int, P]),
     "dance_fuse16w_raw": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int, c_int,
                                   c_int, P]),
     "dance_tail16": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int,

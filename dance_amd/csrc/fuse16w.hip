@@ -15,6 +15,10 @@
 
 using dance::launch_check;
 
+#ifndef DANCE_FUSE_DS
+#define DANCE_FUSE_DS 2
+#endif
+
 namespace {
 
 struct Fuse16wArgs {
@@ -31,9 +35,10 @@ struct Fuse16wArgs {
 };
 
 template <int RT, int CT, int TERMS>
-__device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0, int v, int part, int parts)
+__device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0, int v, int part, int parts,
+                                             long long nn0, int ostep, bool dup)
 {
-    constexpr int NW = 8, CBC = 16, NST = CBC / 4, NCH = 1024 / (CBC * 8), NT = NST * CT;
+    constexpr int NW = 8, CBC = 16, NST = CBC / 4, NCH = 1024 / (CBC * 8), NT = NST * CT, DS = DANCE_FUSE_DS;
     static_assert(CT * 16 <= RT * 32, "the column tiles fit the image");
     using G = Geo<RT, CBC>;
     using S = StageGeo<RT, CBC, NW>;
@@ -46,7 +51,6 @@ __device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0
     const int vs = a.v;
     const long long wbs_b = 512 * 16, wps_b = 128 * wbs_b, wstep_b = 4 * wbs_b;
     const unsigned wlane = (unsigned)(q4 * 512 + c16) * 16u;
-    const int ostep = gridDim.x;
     const char *wbase = reinterpret_cast<const char *>(a.w) + (long long)o0 * 16;
 
     auto chunk_src = [&](long long m, int c) __attribute__((always_inline)) {
@@ -55,7 +59,7 @@ __device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0
                (long long)(cb0 & 15) * vs * 16 + v0 * 16;
     };
 
-    long long nn = blockIdx.x;
+    long long nn = nn0;
     const unsigned lds_base = __builtin_amdgcn_groupstaticsize();   // the dynamic segment follows the static one
     stage_dma<RT, CBC, NW>(0, S::N, chunk_src(nn, 0), lds_base, v, wave, lane, vs);
     stage_dma_wait();
@@ -109,8 +113,10 @@ __device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0
                     // next step's weights: the sequence runs on linearly into the next chunk
                     if (s + 1 < NST || !last)
                         FW_LOAD_A((s + 1) % 2, wchunk + (s + 1) * wstep_b);
-                    if (has_next)
-                        stage_dma<RT, CBC, NW>(s * S::N / NST, (s + 1) * S::N / NST, ssrc, lds_base + nxt, v, wave,
+                    // the next chunk image, issued over the first DS of the chunk's NST K steps so that
+                    // the last loads have NST - DS steps of MFMAs to land behind
+                    if (has_next && s < DS)
+                        stage_dma<RT, CBC, NW>(s * S::N / DS, (s + 1) * S::N / DS, ssrc, lds_base + nxt, v, wave,
                                                lane, vs);
                 }
                 if constexpr (q + 1 < NT)
@@ -160,8 +166,12 @@ __device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0
             if (ce == 0) {
                 float *dst = a.gpart + (nn * parts + part) * 256;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<float4 *>(dst + o0 + 16 * i + 4 * qe) = float4{m[i][0], m[i][1], m[i][2], m[i][3]};
+                for (int i = 0; i < 4; ++i) {
+                    const float4 m4 = float4{m[i][0], m[i][1], m[i][2], m[i][3]};
+                    *reinterpret_cast<float4 *>(dst + o0 + 16 * i + 4 * qe) = m4;
+                    if (dup)                            // a whole ring among split ones: both part slots
+                        *reinterpret_cast<float4 *>(dst + 256 + o0 + 16 * i + 4 * qe) = m4;
+                }
             }
         } else {
             const int p0 = o0 - 256;                        // prediction output channel of row tile 0
@@ -194,9 +204,25 @@ __global__ __launch_bounds__(512) void k_fuse16w(Fuse16wArgs a, int n)
     const int part = blockIdx.y, parts = gridDim.y;
     const int v0 = part * a.part_v, vn = min(a.part_v, a.v - v0);
     if (CTB != CTA && part + 1 == parts)
-        fuse16w_body<RT, CTB, TERMS>(a, n, v0, vn, part, parts);
+        fuse16w_body<RT, CTB, TERMS>(a, n, v0, vn, part, parts, blockIdx.x, gridDim.x, false);
     else
-        fuse16w_body<RT, CTA, TERMS>(a, n, v0, vn, part, parts);
+        fuse16w_body<RT, CTA, TERMS>(a, n, v0, vn, part, parts, blockIdx.x, gridDim.x, false);
+}
+
+// 97..128 vertices, one workgroup per CU: n contours on C CUs run as ceil(n / C) rounds, the last one
+// with n mod C workgroups (1600 on 256: 6.25 -> 7 rounds).  Here the first n_whole contours are whole
+// rings, the rest two half-ring workgroups each (dispatched last, so the last round is one of half the
+// length on twice the CUs); gpart is (n, 2, 256), whole rings write their max to both slots.
+template <int TERMS>
+__global__ __launch_bounds__(512) void k_fuse16w_split(Fuse16wArgs a, int n, int n_whole)
+{
+    const int bx = blockIdx.x;
+    if (bx < n_whole) {
+        fuse16w_body<4, 8, TERMS>(a, n_whole, 0, a.v, 0, 2, bx, n, true);
+    } else {
+        const int idx = bx - n_whole, part = idx & 1, v0 = part * 64;
+        fuse16w_body<2, 4, TERMS>(a, n, v0, min(64, a.v - v0), part, 2, n_whole + (idx >> 1), n, false);
+    }
 }
 
 template <int CTA, int CTB>
@@ -230,6 +256,51 @@ extern "C" int dance_fuse16w_supported(int parts, int v)
     if (parts == 2)
         return v > 96 && v <= 256;
     return 0;
+}
+
+// trailing contours to run as half rings so that the last round of workgroups is a short one: n mod
+// CUs when that is at most half the CUs (and there is more than one round); 97..128 vertices only.
+// DANCE_FUSE16_TAIL_SPLIT=0: never (read per call).
+extern "C" int dance_fuse16w_tail_split(int n, int v)
+{
+    const char *e = getenv("DANCE_FUSE16_TAIL_SPLIT");
+    if ((e && atoi(e) == 0) || v <= 96 || v > 128)
+        return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2)
+        return 0;
+    const int rem = n % cus;
+    return n > cus && rem > 0 && 2 * rem <= cus ? rem : 0;
+}
+
+extern "C" int dance_fuse16w_raw_split(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
+                                       const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
+                                       int64_t y_slot_stride, float *gpart2, int n, int v, int n_split,
+                                       int mfma_terms, void *stream)
+{
+    DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
+    DANCE_REQUIRE(n >= 1 && v > 96 && v <= 128 && n_split >= 1 && n_split <= n);
+    DANCE_REQUIRE(x && w16 && bias_scaled && y16 && gpart2);
+    Fuse16wArgs a;
+    a.x = (const _Float16 *)x; a.x_stride = x_stride; a.x_slot_stride = x_slot_stride;
+    a.w = (const h8 *)w16; a.bias_s = bias_scaled; a.winv = w_inv_scale;
+    a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
+    a.gpart = gpart2; a.part_v = 64;
+    const size_t lds = (size_t)2 * Geo<4, 16>::BYTES;
+    const int n_whole = n - n_split;
+    dim3 grid(n_whole + 2 * n_split);
+    int rc;
+    if (mfma_terms == 1) {
+        if ((rc = dance::allow_lds((const void *)k_fuse16w_split<1>, lds, "dance_fuse16w_raw_split")))
+            return rc;
+        hipLaunchKernelGGL((k_fuse16w_split<1>), grid, dim3(512), lds, (hipStream_t)stream, a, n, n_whole);
+    } else {
+        if ((rc = dance::allow_lds((const void *)k_fuse16w_split<3>, lds, "dance_fuse16w_raw_split")))
+            return rc;
+        hipLaunchKernelGGL((k_fuse16w_split<3>), grid, dim3(512), lds, (hipStream_t)stream, a, n, n_whole);
+    }
+    return launch_check("dance_fuse16w_raw_split");
 }
 
 extern "C" int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,

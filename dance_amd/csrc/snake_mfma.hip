@@ -675,11 +675,19 @@ int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, bool h
     static const int use_tail = getenv("DANCE_TAIL16") ? atoi(getenv("DANCE_TAIL16")) : 1;
     if (use_tail) {
         const int parts = dance_fuse16_parts(n, v);
+        int tail_parts = parts;
         float *gpart = w.gmax;                  // (n, parts <= 2, 256): gmax and h are adjacent pieces
         DANCE_REQUIRE(w.h == w.gmax + (long long)n * 256);
         // the fusion kernel on 16-wide vertex tiles (fuse16w.hip); DANCE_FUSE16_SHAPE=32: k_fuse16r
         static const int fuse_shape = getenv("DANCE_FUSE16_SHAPE") ? atoi(getenv("DANCE_FUSE16_SHAPE")) : 16;
-        if (fuse_shape == 16 && dance_fuse16w_supported(parts, v))
+        // one part per contour and a last round of workgroups that is mostly empty: its contours as
+        // half rings (fuse16w.hip, k_fuse16w_split); the tail kernel then reads two part slots
+        const int n_split = fuse_shape == 16 && parts == 1 ? dance_fuse16w_tail_split(n, v) : 0;
+        if (n_split > 0) {
+            DANCE_TRY(dance_fuse16w_raw_split(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
+                                              pstride, slot, gpart, n, v, n_split, mfma_terms, stream));
+            tail_parts = 2;
+        } else if (fuse_shape == 16 && dance_fuse16w_supported(parts, v))
             DANCE_TRY(dance_fuse16w_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
                                         pstride, slot, gpart, n, v, parts, mfma_terms, stream));
         else
@@ -689,7 +697,7 @@ int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, bool h
         DANCE_TRY(mark());      // row constant: inside the tail kernel
         DANCE_TRY(mark());      // prediction[0]'s ReLU: inside the tail kernel
         DANCE_TRY(mark());      // prediction[2]: the tail kernel, booked on the last stage
-        DANCE_TRY(dance_tail16(p1, pstride, slot, gpart, parts, net->pred0_wg, net->pred0_b, net->pred1_w,
+        DANCE_TRY(dance_tail16(p1, pstride, slot, gpart, tail_parts, net->pred0_wg, net->pred0_b, net->pred1_w,
                                net->pred1_bs, net->pred1_winv, net->pred2_w, net->pred2_b, loc,
                                whs, att_s, out, n, v,
                                clip_first, clip_x_max, clip_y_max, mfma_terms, stream));

@@ -452,6 +452,21 @@ int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, co
                       int64_t y_slot_stride, float *gpart, int n, int v, int parts, int mfma_terms,
                       void *stream);
 
+/* dance_fuse16w_raw for rings of 97..128 vertices whose LAST n_split contours run as two half-ring
+ * workgroups each: the kernel holds one workgroup per CU, so n contours take ceil(n / CUs) rounds and
+ * the last round of n mod CUs workgroups costs as much as a full one (1600 contours on 256 CUs: 6.25
+ * -> 7 rounds); as half rings it takes about half as long on twice the CUs.  gpart2 is (n, 2, 256):
+ * whole rings write their max to both part slots, so dance_tail16 is called with parts = 2.
+ * dance_fuse16w_tail_split(n, v): the n_split dance_snake_evolve16 uses -- n mod CUs when there is more
+ * than one round and that remainder fills at most half the CUs, else 0 (DANCE_FUSE16_TAIL_SPLIT=0:
+ * always 0).  Outputs bit-identical to dance_fuse16w_raw with one part (same products, same
+ * order; the max over a ring is the max of its halves' maxima).  reference: as dance_fuse16w_raw. */
+int dance_fuse16w_tail_split(int n, int v);
+int dance_fuse16w_raw_split(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
+                            const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
+                            int64_t y_slot_stride, float *gpart2, int n, int v, int n_split,
+                            int mfma_terms, void *stream);
+
 /* The end of a _SnakeNet and of evolve in one launch: global state = max over gpart's parts ->
  * row constant h = pred0_bias + wg^T g (as dance_row_constant) -> relu(p1 + h) -> prediction[2]
  * (w1_16: packed (2,1,32,64,8), b1_scaled, w1_inv_scale) + ReLU -> prediction[4] + offset update

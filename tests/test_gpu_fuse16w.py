@@ -48,3 +48,70 @@ def test_fuse16w_support_table(device):
     assert [f(1, v) for v in (12, 16, 96, 128, 129)] == [0, 1, 1, 1, 0]
     assert [f(2, v) for v in (96, 97, 128, 160, 256, 260)] == [0, 1, 1, 1, 1, 0]
     assert f(3, 128) == 0
+
+
+@pytest.mark.parametrize("n,v,n_split", [(300, 128, 44), (300, 100, 44), (9, 112, 9), (40, 97, 1), (300, 128, 300)])
+def test_fuse16w_split_tail_equals_whole(device, n, v, n_split):
+    """dance_fuse16w_raw_split (the last n_split contours as two half-ring workgroups each, the rest
+    whole; gpart (n, 2, 256) with whole rings' max in both slots) against dance_fuse16w_raw with one
+    part: prediction[0] state part bit-identical, the max over the two part slots bit-identical."""
+    cfg, sd, _ = dance_state_dict(43, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer2."), device)
+    s16 = net.struct16
+    g = torch.Generator().manual_seed(v + n)
+    x = torch.randn((n, 1024, v), generator=g)
+    x[1, :, 3] = float("nan")                                  # NaN travels through the max as in torch
+    state = ops.to_p16(x.to(device))
+    slot = 256 * v
+    for terms in (3, 1):
+        gw, pw = _run("dance_fuse16w_raw", s16, state, n, v, 1, terms)
+        gs = torch.full((n, 2, 256), float("nan"), device=device)
+        p1 = torch.zeros((n, 2, 2, 16, v, 8), dtype=torch.float16, device=device)
+        with torch.cuda.device(device):
+            check(lib().dance_fuse16w_raw_split(ptr(state), state.stride(0), slot, s16.fuse_w, s16.fuse_bs,
+                                                s16.fuse_winv, ptr(p1), p1.stride(0), slot, ptr(gs), n, v, n_split,
+                                                terms, current_stream()), "fuse16w_raw_split")
+        ps = ops.from_p16(p1)
+        assert torch.equal(torch.nan_to_num(ps, nan=7.0), torch.nan_to_num(pw, nan=7.0))
+        whole = gs[:n - n_split]
+        assert torch.equal(torch.nan_to_num(whole[:, 0], nan=7.0), torch.nan_to_num(whole[:, 1], nan=7.0))
+        m = torch.maximum(gs[:, 0], gs[:, 1])                  # torch.maximum propagates NaN
+        assert torch.equal(torch.nan_to_num(m, nan=7.0), torch.nan_to_num(gw[:, 0], nan=7.0))
+
+
+def test_fuse16w_tail_split_rule(device, monkeypatch):
+    """n mod CUs contours when there is more than one round and they fill at most half the CUs"""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    f = lib().dance_fuse16w_tail_split
+    with torch.cuda.device(device):
+        assert f(cus, 128) == 0 and f(cus - 1, 128) == 0 and f(6 * cus, 128) == 0
+        assert f(6 * cus + 64, 128) == 64 and f(6 * cus + cus // 2, 100) == cus // 2
+        assert f(6 * cus + cus // 2 + 1, 128) == 0
+        assert f(6 * cus + 64, 96) == 0 and f(6 * cus + 64, 132) == 0
+        monkeypatch.setenv("DANCE_FUSE16_TAIL_SPLIT", "0")
+        assert f(6 * cus + 64, 128) == 0
+
+
+def test_evolve_with_split_tail_is_bit_identical(device, monkeypatch):
+    """one iteration over CUs + 44 contours: the evolve sequence with the fusion kernel's last round as
+    half rings (default) against DANCE_FUSE16_TAIL_SPLIT=0"""
+    from dance_amd import synthetic
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    n, v, b, hf, wf = cus + 44, 128, 2, 40, 56
+    cfg, sd, _ = dance_state_dict(44, v)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    d = snake.ContourDeformer(nets)
+    feats = synthetic.make_features(b, 256, hf, wf, 3).to(device)
+    f = d.prepare_features(feats)
+    boxes = synthetic.make_boxes(n, hf * 4, wf * 4, 5)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1).to(device)
+    init, _ = ops.uniform_upsample(boxes.to(device), v, kind=ops.POLY_BOX)
+    idx = (torch.arange(n) % b).to(torch.int32).to(device)
+    with torch.cuda.device(device):
+        assert lib().dance_fuse16w_tail_split(n, v) == 44
+    a = d.evolve(1, *f, init, idx, whs, use_att=True, clip_first=False, clip_max=(0, 0))
+    monkeypatch.setenv("DANCE_FUSE16_TAIL_SPLIT", "0")
+    with torch.cuda.device(device):
+        assert lib().dance_fuse16w_tail_split(n, v) == 0
+    b_ = d.evolve(1, *f, init, idx, whs, use_att=True, clip_first=False, clip_max=(0, 0))
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b_)
