@@ -81,6 +81,7 @@ def test_fuse16w_split_tail_equals_whole(device, n, v, n_split):
 
 def test_fuse16w_tail_split_rule(device, monkeypatch):
     """n mod CUs contours when there is more than one round and they fill at most half the CUs"""
+    monkeypatch.delenv("DANCE_FUSE16_TAIL_SPLIT", raising=False)
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     f = lib().dance_fuse16w_tail_split
     with torch.cuda.device(device):
@@ -96,6 +97,7 @@ def test_evolve_with_split_tail_is_bit_identical(device, monkeypatch):
     """one iteration over CUs + 44 contours: the evolve sequence with the fusion kernel's last round as
     half rings (default) against DANCE_FUSE16_TAIL_SPLIT=0"""
     from dance_amd import synthetic
+    monkeypatch.delenv("DANCE_FUSE16_TAIL_SPLIT", raising=False)
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     n, v, b, hf, wf = cus + 44, 128, 2, 40, 56
     cfg, sd, _ = dance_state_dict(44, v)
