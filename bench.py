@@ -255,7 +255,11 @@ def main():
     # one kernel sequence per iteration up to CHUNK_CAP contours, chunks of CHUNK_CAP beyond
     single_chunk = n <= CHUNK_CAP
     deformer.MAX_CHUNK = n if single_chunk else CHUNK_CAP
-    n_ev = min(n, CHUNK_CAP)                                  # contours of the launches the events time
+    # deform() peels n mod CUs contours off to a side stream so that the main stream's kernels run whole
+    # rounds of workgroups (ContourDeformer.peel_count; DANCE_PEEL=0: off).  The timed events sit on the
+    # main stream: they time launches of n - side_n contours, and the roofline uses that count.
+    side_n = deformer.peel_count(n, dev) if single_chunk and args.streams == 1 else 0
+    n_ev = min(n, CHUNK_CAP) - side_n                         # contours of the launches the events time
 
     # synthetic inputs, resident in HBM before the timed region
     feats = torch.empty((b, CH + 1, HF, WF), dtype=torch.float32, device=dev)
@@ -768,6 +772,11 @@ def main():
                                   "`offset_update` is k_tail16 (row constant, ReLU, prediction[2], prediction[4], "
                                   "offset update); row_constant / pred0 / pred1 are inside those two launches"),
             "streams": args.streams,
+            "peel": {"main_stream_contours": n - side_n, "side_stream_contours": side_n,
+                     "note": "deform() runs n mod CUs contours as their own kernel chain on a side HIP stream, so the "
+                             "main stream's launches are whole rounds of workgroups (bit-identical results; "
+                             "DANCE_PEEL=0 keeps one stream).  All n contours are inside the timed region; the "
+                             "stage events and the roofline time the main stream's launches"},
             "two_streams": two_streams,
             "feat_prep": feat_prep,
             "mask_rle": mask_rle,

@@ -140,6 +140,16 @@ def sub_state_dict(sd, prefix):
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
+_CUS = {}
+
+
+def _cu_count(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _CUS:
+        _CUS[key] = torch.cuda.get_device_properties(key).multi_processor_count
+    return _CUS[key]
+
+
 class ContourDeformer:
     """Iterative contour deformation on one GPU.
 
@@ -198,6 +208,7 @@ class ContourDeformer:
         parts = []
         for i, (st, d) in enumerate(self._side):
             d.MAX_CHUNK = self.MAX_CHUNK
+            d._no_peel = True                    # a part of a split batch is not split again
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 sl = slice(cuts[i], cuts[i + 1])
@@ -209,6 +220,49 @@ class ContourDeformer:
             for t in p:
                 t.record_stream(cur)
         return [torch.cat([p[i] for p in parts]) for i in range(len(self.nets))]
+
+    def peel_count(self, n, device):
+        """Contours deform() hands to a side stream so that the main stream's kernels run whole rounds
+        of workgroups: n mod CUs.  Every kernel of the sequence is one workgroup per contour with 1-3
+        resident per CU, so a batch that is not a multiple of the CU count pays nearly a full round for
+        its remainder in every kernel (BASELINE config 2's 1600 contours on 256 CUs: 6.25 rounds,
+        ~5 % of the step).  The remainder's own kernel chain is small and overlaps the main
+        one.  0 = no peel: batches below two rounds, chunked batches, under stream capture,
+        DANCE_PEEL=0.  Results are bit-identical either way (contours are independent)."""
+        if os.environ.get("DANCE_PEEL", "1") == "0" or device.type != "cuda" or getattr(self, "_no_peel", False):
+            return 0
+        cus = _cu_count(device)
+        if n < 2 * cus or n > self.MAX_CHUNK or n % cus == 0 or torch.cuda.is_current_stream_capturing():
+            return 0
+        return n % cus
+
+    def _deform_peeled(self, features, init_contours, image_idx, image_sizes, whs, layout, stage_events, side_n):
+        feat_att = self.prepare_features(features) if layout == "nchw" else features
+        n, v = init_contours.shape[:2]
+        m = n - side_n
+        dev = init_contours.device
+        cur = torch.cuda.current_stream(dev)
+        if getattr(self, "_peel_side", None) is None:
+            self._peel_side = (torch.cuda.Stream(dev),
+                               ContourDeformer(self.nets, self._padding_name, self._deloc_name, self.individual_scale,
+                                               self.attention, self.fused_head, self.precision))
+        st, side = self._peel_side
+        side._no_peel = True
+        locations = init_contours.contiguous().float()
+        whs = None if whs is None else whs.contiguous().float()
+        idx = image_idx.to(torch.int32).contiguous()
+        preds = [torch.empty((n, v, 2), dtype=torch.float32, device=dev) for _ in self.nets]
+        feat, att = feat_att
+        st.wait_stream(cur)                      # features, inputs and the output buffers exist
+        for d, lo, hi, stream, ev in ((side, m, n, st, None), (self, 0, m, cur, stage_events)):
+            with torch.cuda.stream(stream):
+                prev = locations[lo:hi]
+                for i in range(len(self.nets)):
+                    prev = d.evolve(i, feat, att, prev, idx[lo:hi], None if whs is None else whs[lo:hi],
+                                    use_att=(self.attention and i > 0), clip_first=False, clip_max=(0.0, 0.0),
+                                    out=preds[i][lo:hi], stage_events=None if ev is None else ev[i])
+        cur.wait_stream(st)                      # everything the side stream touched is ordered before what follows
+        return preds
 
     def evolve(self, it, feat, att, locations, image_idx, whs, *, use_att, clip_first, clip_max,
                x_in=None, out=None, stage_events=None):
@@ -320,6 +374,10 @@ class ContourDeformer:
         config 2; results bit-identical)."""
         if streams > 1 and init_contours.size(0) >= 2 * streams and stage_events is None and image_idx is not None:
             return self._deform_streams(features, init_contours, image_idx, image_sizes, whs, layout, streams)
+        side_n = self.peel_count(init_contours.size(0), init_contours.device) if image_idx is not None else 0
+        if side_n:
+            return self._deform_peeled(features, init_contours, image_idx, image_sizes, whs, layout, stage_events,
+                                       side_n)
         if layout == "nchw":
             feat, att = self.prepare_features(features)
         else:

@@ -158,3 +158,46 @@ def test_dsnake_two_streams_equal_one_stream(device, monkeypatch):
     for _ in range(3):
         for a, r in zip(run(2), ref):
             assert torch.equal(a, r)
+
+
+def test_peeled_remainder_equals_one_stream(device, monkeypatch):
+    """BASELINE config 2's count (16 x 100 = 1600 contours = 6.25 x 256 CUs): deform() hands n mod CUs
+    contours to a side HIP stream (ContourDeformer.peel_count) so that the main stream's kernels run
+    whole rounds of workgroups; three runs, every iteration bit-identical to the one-stream result
+    (DANCE_PEEL=0), and stage events still arrive on the main stream."""
+    monkeypatch.delenv("DANCE_PEEL", raising=False)
+    b, per, v = 16, 100, 128
+    cfg, sd, _ = dance_state_dict(1235, v)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    feats = _features(b, 256, 501, device)
+    boxes, whs, init, idx = _dance_inputs(b, per, v, 81, device)
+    d = snake.ContourDeformer(nets)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    with torch.cuda.device(device):
+        side_n = d.peel_count(b * per, torch.device(device))
+    assert side_n == (b * per) % cus
+    if side_n == 0:
+        pytest.skip("1600 is a multiple of this GPU's CU count")
+    f = d.prepare_features(feats)
+    runs = [d.deform(f, init, idx.to(device), [(HF * 4, WF * 4)] * b, whs.to(device), layout="nhwc") for _ in range(3)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(snake.EVOLVE_EVENTS)] for _ in range(3)]
+    for it_ev in ev:
+        for e in it_ev:
+            e.record()                                          # creates the handle the library records into
+    timed = d.deform(f, init, idx.to(device), [(HF * 4, WF * 4)] * b, whs.to(device), layout="nhwc", stage_events=ev)
+    torch.cuda.synchronize()
+    assert ev[0][0].elapsed_time(ev[2][-1]) > 0
+    monkeypatch.setenv("DANCE_PEEL", "0")
+    with torch.cuda.device(device):
+        assert d.peel_count(b * per, torch.device(device)) == 0
+    one = d.deform(f, init, idx.to(device), [(HF * 4, WF * 4)] * b, whs.to(device), layout="nhwc")
+    for it in range(3):
+        assert bool(torch.isfinite(one[it]).all())
+        for r in runs + [timed]:
+            assert torch.equal(r[it], one[it]), it
+    # a short batch, a multiple of the CU count and a chunked batch are not peeled
+    monkeypatch.delenv("DANCE_PEEL")
+    with torch.cuda.device(device):
+        assert d.peel_count(2 * cus - 1, torch.device(device)) == 0
+        assert d.peel_count(6 * cus, torch.device(device)) == 0
+        assert d.peel_count(d.MAX_CHUNK + 1, torch.device(device)) == 0
