@@ -33,6 +33,22 @@ inline int launch_check(const char *fn)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// compute units of the current device (0 when the query fails); cached per device
+inline int cu_count()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 0;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return 0;
+        cached[dev] = cus;
+    }
+    return cached[dev];
+}
+
 // A launch with more than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize
 // raised on the kernel -- per DEVICE (the attribute lives with the device's copy of the code
 // object).  Issued once per (kernel, device), again only when a larger size is asked for;
