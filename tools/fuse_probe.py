@@ -1,4 +1,4 @@
-"""Time dance_fuse16_raw alone (n contours x v vertices, random state and the synthetic weights):
+"""Time dance_fuse16w_raw alone (n contours x v vertices, random state and the synthetic weights):
 python tools/fuse_probe.py [n] [v] [reps].  Used for A/B runs of library variants (DANCE_HIP_LIB)."""
 import os
 import sys
@@ -29,8 +29,8 @@ p1 = torch.zeros((n, 2, 2, 16, v, 8), dtype=torch.float16, device=dev)
 
 
 def run():
-    check(lib().dance_fuse16_raw(ptr(state), state.stride(0), slot, s16.fuse_w, s16.fuse_bs, s16.fuse_winv,
-                                 ptr(p1), p1.stride(0), slot, ptr(gpart), n, v, 3, current_stream()), "fuse16_raw")
+    check(lib().dance_fuse16w_raw(ptr(state), state.stride(0), slot, s16.fuse_w, s16.fuse_bs, s16.fuse_winv,
+                                  ptr(p1), p1.stride(0), slot, ptr(gpart), n, v, parts, 3, current_stream()), "fuse16w_raw")
 
 
 for _ in range(5):
