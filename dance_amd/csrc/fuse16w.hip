@@ -330,14 +330,18 @@ extern "C" int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot
     a.gpart = gpart;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = dance::ceil_div(v, 16);
-    if (parts == 1) {                           // instantiated tile counts: 3, 4, 6, 8
+    if (parts == 1) {                           // instantiated tile counts: 3 .. 8
         a.part_v = v;
         if (tiles <= 3)
             return launch_fuse<3, 3>(a, n, 1, mfma_terms, s);
         if (tiles <= 4)
             return launch_fuse<4, 4>(a, n, 1, mfma_terms, s);
-        if (tiles <= 6)
+        if (tiles == 5)
+            return launch_fuse<5, 5>(a, n, 1, mfma_terms, s);
+        if (tiles == 6)
             return launch_fuse<6, 6>(a, n, 1, mfma_terms, s);
+        if (tiles == 7)
+            return launch_fuse<7, 7>(a, n, 1, mfma_terms, s);
         return launch_fuse<8, 8>(a, n, 1, mfma_terms, s);
     }
     // two parts: the first of CTA full tiles, the second what remains (at most CTB tiles)

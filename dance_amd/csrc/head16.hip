@@ -490,14 +490,29 @@ extern "C" int dance_gather_head16w(const float *feat, const float *att, const f
         if (n <= (e ? atoi(e) : 128))
             return v <= 96 ? launch_head_halves<2, 3>(a, n, mfma_terms, s) : launch_head_halves<3, 4>(a, n, mfma_terms, s);
     }
+    const int ct = (v + 15) / 16;
+    // 129..208 vertices (9..13 tiles) as two half rings of 5, 6 or 7 tiles as well: twice the
+    // workgroups, three per CU (DANCE_HEAD_HALVES_MID=0: one workgroup per contour, two per CU)
+    if (v > 128) {
+        const char *e = getenv("DANCE_HEAD_HALVES_MID");
+        if (!(e && atoi(e) == 0)) {
+            if (ct <= 10)
+                return launch_head_halves<3, 5>(a, n, mfma_terms, s);
+            return ct <= 12 ? launch_head_halves<4, 6>(a, n, mfma_terms, s) : launch_head_halves<4, 7>(a, n, mfma_terms, s);
+        }
+    }
     const int rtg = v <= 64 ? 2 : (v <= 128 ? 4 : 7);
     const size_t lds = (size_t)2 * 8 * (rtg * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
-    const int ct = (v + 15) / 16;
     if (rtg == 2)
         return ct <= 2 ? launch_head<2, 2>(a, n, mfma_terms, lds, s)
                        : (ct == 3 ? launch_head<2, 3>(a, n, mfma_terms, lds, s) : launch_head<2, 4>(a, n, mfma_terms, lds, s));
-    if (rtg == 4)
-        return ct <= 6 ? launch_head<4, 6>(a, n, mfma_terms, lds, s) : launch_head<4, 8>(a, n, mfma_terms, lds, s);
+    if (rtg == 4) {
+        if (ct <= 5)
+            return launch_head<4, 5>(a, n, mfma_terms, lds, s);
+        if (ct == 6)
+            return launch_head<4, 6>(a, n, mfma_terms, lds, s);
+        return ct == 7 ? launch_head<4, 7>(a, n, mfma_terms, lds, s) : launch_head<4, 8>(a, n, mfma_terms, lds, s);
+    }
     if (ct <= 10)
         return launch_head<7, 10>(a, n, mfma_terms, lds, s);
     if (ct <= 12)

@@ -383,7 +383,7 @@ struct Stack16Args {
 template <int RT, int TERMS, int CT = 2 * RT>
 __device__ __forceinline__ void res_stack16_layers(const Stack16Args &a, long long nn, char *xs)
 {
-    static_assert(RT <= 4, "rings of at most 128 vertices");
+    static_assert(RT <= 4 && CT * 16 <= RT * 32, "rings of at most 128 vertices, the tiles inside the image");
     constexpr int CBC = 8, NST = CBC / 4, AD = 2, NB = (NST * CT) % 4 == 0 ? 4 : 2;
     using G = Geo<RT, CBC>;
     const int t = threadIdx.x, lane = t & 63;
@@ -561,7 +561,7 @@ __device__ __forceinline__ void res_stack16w_layers(const Stack16Args &a, _Float
 template <int RT, int CTB, int TERMS>
 __device__ __forceinline__ void res_stack16w_body(const Stack16Args &a, int n)
 {
-    static_assert(RT == 4 || RT == 7 || RT == 8, "rings of 97..128 (few contours) or 129..256 vertices");
+    static_assert(RT >= 4 && RT <= 8, "rings of 97..128 (few contours) or 129..256 vertices");
     static_assert(CTB == RT || CTB == RT - 1, "the second group of waves takes as many tiles or one fewer");
     constexpr int CBC = 8, NW = 8;
     using G = Geo<RT, CBC>;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512) void k_res_stack16w(Stack16Args a, int n)
     res_stack16w_body<RT, RT, TERMS>(a, n);
 }
 
-// 13 tiles (193..208 vertices, the shipped yamls' 196): 7 + 6
+// an odd number of tiles: 13 (193..208 vertices, the shipped yamls' 196) as 7 + 6, 9 as 5 + 4, 11 as 6 + 5
 template <int RT, int TERMS>
 __global__ __launch_bounds__(512) void k_res_stack16w13(Stack16Args a, int n)
 {
@@ -1269,7 +1269,12 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
         a.w[i] = (const h8 *)net->res_w[i]; a.bias_s[i] = net->res_bs[i]; a.scale[i] = net->res_scale[i];
         a.shift[i] = net->res_shift[i]; a.winv[i] = net->res_winv[i]; a.dilation[i] = net->dilation[i];
     }
-    const int rt = pick_rt16(v);
+    int rt = pick_rt16(v);
+    // 129..192 vertices: images of 160 / 192 columns (5 + 5, 6 + 6 vertex tiles, or one fewer in the
+    // second group of waves) instead of 224 (DANCE_STACK_MID=0: 224 columns, 7 + 7 tiles)
+    static const int mid = env_int("DANCE_STACK_MID", 1);
+    if (mid && v > 128 && v <= 192)
+        rt = v <= 160 ? 5 : 6;
     const size_t lds = (size_t)2 * 2 * 8 * (rt * 32 + 1) * 16;     // the whole 128-channel image
     // few contours (the reference's one-image inference: ~100 instances on 256 CUs): a contour per
     // CU either way, so it gets 8 waves instead of 4 (-9 % on the stack at n = 100; same products
@@ -1283,8 +1288,18 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
             LAUNCH_ONE(k_res_stack16w, 4, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
         else if (rt == 7 && v > 192 && v <= 208 && odd_split)
             LAUNCH_ONE(k_res_stack16w13, 7, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else if (rt == 5 && v <= 144 && odd_split)                 // 9 tiles: 5 + 4
+            LAUNCH_ONE(k_res_stack16w13, 5, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else if (rt == 5)
+            LAUNCH_ONE(k_res_stack16w, 5, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else if (rt == 6 && v <= 176 && odd_split)                 // 11 tiles: 6 + 5
+            LAUNCH_ONE(k_res_stack16w13, 6, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else if (rt == 6)
+            LAUNCH_ONE(k_res_stack16w, 6, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
         else if (rt == 7)
             LAUNCH_ONE(k_res_stack16w, 7, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
+        else if (mid && v <= 240 && odd_split)                     // 15 tiles: 8 + 7
+            LAUNCH_ONE(k_res_stack16w13, 8, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
         else
             LAUNCH_ONE(k_res_stack16w, 8, mfma_terms, dim3(n), dim3(512), lds, (hipStream_t)stream, "dance_res_stack16", a, n);
         if (rc_)
@@ -1296,6 +1311,35 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
             hipLaunchKernelGGL((k_res_stack16s<2, 1, 3>), dim3(n), dim3(256), lds, (hipStream_t)stream, a, n);
         else
             hipLaunchKernelGGL((k_res_stack16s<2, 3, 3>), dim3(n), dim3(256), lds, (hipStream_t)stream, a, n);
+        return launch_check(__func__);
+    }
+    if (mid && v > 64 && v <= 112) {
+        // 65..112 vertices: 5, 6 or 7 of the 16-wide vertex tiles instead of 8 (up to 96 vertices in a
+        // 96-column image: 50 KB of LDS, three workgroups per CU)
+        const int tiles = dance::ceil_div(v, 16);
+        const size_t lds3 = (size_t)2 * 2 * 8 * (3 * 32 + 1) * 16;
+        int rc_ = 0;
+#define STACK_S(RTV, CTV, LDS)                                                                     \
+    do {                                                                                           \
+        if (mfma_terms == 1) {                                                                     \
+            rc_ = big_lds(k_res_stack16s<RTV, 1, CTV>, LDS, "dance_res_stack16");                  \
+            if (!rc_)                                                                              \
+                hipLaunchKernelGGL((k_res_stack16s<RTV, 1, CTV>), dim3(n), dim3(256), LDS, (hipStream_t)stream, a, n); \
+        } else {                                                                                   \
+            rc_ = big_lds(k_res_stack16s<RTV, 3, CTV>, LDS, "dance_res_stack16");                  \
+            if (!rc_)                                                                              \
+                hipLaunchKernelGGL((k_res_stack16s<RTV, 3, CTV>), dim3(n), dim3(256), LDS, (hipStream_t)stream, a, n); \
+        }                                                                                          \
+    } while (0)
+        if (tiles <= 5)
+            STACK_S(3, 5, lds3);
+        else if (tiles == 6)
+            STACK_S(3, 6, lds3);
+        else
+            STACK_S(4, 7, lds);
+#undef STACK_S
+        if (rc_)
+            return rc_;
         return launch_check(__func__);
     }
     LAUNCH_RT24(k_res_stack16s, rt, mfma_terms, dim3(n), dim3(256), lds, (hipStream_t)stream, "dance_res_stack16", a, n);

@@ -38,7 +38,7 @@ def _inputs(device, v, n=29, seed=5):
     return nhwc, att, loc, idx
 
 
-@pytest.mark.parametrize("v", [16, 20, 32, 36, 40, 48, 64, 68, 96, 100, 128, 132, 160, 164, 192, 196, 208,
+@pytest.mark.parametrize("v", [16, 20, 32, 36, 40, 48, 64, 68, 80, 96, 100, 112, 128, 132, 160, 164, 192, 196, 208,
                                209, 212, 224, 225, 240, 241, 250, 256])
 def test_head16w_equals_head16(device, v):
     """every instantiated tile count; above 208 vertices the ring runs as two half rings (tiles split
@@ -75,6 +75,24 @@ def test_head16w_small_n_half_rings(device, v, monkeypatch):
         halves, att_h = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, 37, v, ops.PAD_REFLECTION,
                              ops.DELOC[deloc], terms)
         assert torch.equal(halves, whole)                       # same K order per output: bit-identical
+        assert torch.equal(att_h, att_w)
+
+
+@pytest.mark.parametrize("v", [129, 132, 160, 164, 192, 196, 208])
+def test_head16w_mid_half_rings(device, v, monkeypatch):
+    """129..208-vertex rings run as two half rings of 5, 6 or 7 tiles (default) -- against the
+    one-workgroup-per-contour kernels (DANCE_HEAD_HALVES_MID=0): same K order per output, bit-identical"""
+    cfg, sd, _ = dance_state_dict(83, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer2."), device)
+    nhwc, att, loc, idx = _inputs(device, v, n=21)
+    for terms, deloc in [(3, "derange"), (1, "demean")]:
+        monkeypatch.setenv("DANCE_HEAD_HALVES_MID", "0")
+        whole, att_w = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, 21, v, ops.PAD_REFLECTION,
+                            ops.DELOC[deloc], terms)
+        monkeypatch.delenv("DANCE_HEAD_HALVES_MID")
+        halves, att_h = _run("dance_gather_head16w", net.struct16, nhwc, att, loc, idx, 21, v, ops.PAD_REFLECTION,
+                             ops.DELOC[deloc], terms)
+        assert torch.equal(halves, whole)
         assert torch.equal(att_h, att_w)
 
 

@@ -275,7 +275,7 @@ def test_deterministic_and_chunked(device):
         assert coord_rel_err(a[i], want[i]) < REL_TOL
 
 
-@pytest.mark.parametrize("v", [16, 40, 64, 100, 128, 132, 196, 208, 224, 228, 256])
+@pytest.mark.parametrize("v", [16, 40, 64, 68, 80, 96, 100, 112, 128, 132, 144, 148, 160, 164, 176, 180, 192, 196, 208, 224, 228, 256])
 def test_res_stack_equals_seven_launches(device, v):
     """dance_res_stack16 (7 residual blocks, activations resident in LDS) against 7 dance_conv16
     launches through HBM, for both MFMA term counts: bit-identical up to 128 vertices."""
@@ -285,8 +285,9 @@ def test_res_stack_equals_seven_launches(device, v):
     net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
     s16 = net.struct16
     slot = 256 * v
-    # 97..128 vertices: up to 256 contours run the 8-wave kernel, more the 4-wave one -- cover both
-    for n, terms in [(37, 3), (37, 1)] + ([(300, 3), (300, 1)] if 96 < v <= 128 else []):
+    # 65..128 vertices: up to 256 contours run the 8-wave kernel, more the 4-wave one (5, 6, 7 or 8 vertex
+    # tiles) -- cover both
+    for n, terms in [(37, 3), (37, 1)] + ([(300, 3), (300, 1)] if 64 < v <= 128 else []):
         x = torch.randn((n, 128, v), generator=torch.Generator().manual_seed(v)) * 2
         a = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
         a[:, 0] = ops.to_p16(x.to(device))[:, 0]
