@@ -351,11 +351,11 @@ extern "C" int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot
     }
     if (tiles <= 10) {
         a.part_v = 80;
-        return launch_fuse<5, 5>(a, n, 2, mfma_terms, s);
+        return tiles == 9 ? launch_fuse<5, 4>(a, n, 2, mfma_terms, s) : launch_fuse<5, 5>(a, n, 2, mfma_terms, s);
     }
     if (tiles <= 12) {
         a.part_v = 96;
-        return launch_fuse<6, 6>(a, n, 2, mfma_terms, s);
+        return tiles == 11 ? launch_fuse<6, 5>(a, n, 2, mfma_terms, s) : launch_fuse<6, 6>(a, n, 2, mfma_terms, s);
     }
     if (tiles == 13) {
         a.part_v = 112;
@@ -366,5 +366,5 @@ extern "C" int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot
         return launch_fuse<7, 7>(a, n, 2, mfma_terms, s);
     }
     a.part_v = 128;
-    return launch_fuse<8, 8>(a, n, 2, mfma_terms, s);
+    return tiles == 15 ? launch_fuse<8, 7>(a, n, 2, mfma_terms, s) : launch_fuse<8, 8>(a, n, 2, mfma_terms, s);
 }

@@ -24,7 +24,7 @@ def _run(fn, s16, state, n, v, parts, terms):
 
 
 @pytest.mark.parametrize("n,v", [(7, 100), (7, 128), (300, 112), (300, 128), (9, 196), (200, 208), (9, 244), (150, 256),
-                                 (300, 16), (300, 40), (9, 48), (300, 64), (300, 68), (300, 80), (9, 96), (9, 132), (9, 160),
+                                 (300, 16), (300, 40), (9, 48), (300, 64), (300, 68), (300, 80), (9, 96), (9, 132), (300, 144), (9, 160), (300, 176), (300, 236),
                                  (200, 164), (9, 192), (9, 212), (200, 224), (9, 228), (9, 240),
                                  # whole rounds of the CUs: one persistent workgroup per CU loops over its
                                  # contours (next contour's first chunk staged behind the current one)
