@@ -414,3 +414,29 @@ def test_conv16_pointwise_forms(device, v):
     want3 = torch.relu(torch.nn.functional.conv1d(x256, w64, b[:64]))
     assert y64.shape == (n, 64, v)
     assert rel_err(y64, want3, floor=float(want3.abs().max())) < 1e-5
+
+
+@pytest.mark.parametrize("n,v", [(270, 80), (270, 96), (270, 112), (40, 144), (40, 160), (40, 176), (40, 192),
+                                 (40, 240)])
+def test_every_tile_count_vs_oracle(device, n, v):
+    """Ring lengths between the benchmarked ones run kernels of their own tile counts (5 / 6 / 7-tile
+    stack, head and fusion forms at more than 256 contours; 160 / 192-column stack images, half-ring
+    heads, odd tile splits above 128 vertices): every iteration on identical inputs against the oracle,
+    1e-4 norm-wise and 0.02 px (RefineNet.evolve snake_head.py:1624-1713)."""
+    cfg, sd, _ = dance_state_dict(4000 + v, v)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    b, hf, wf = 2, 50, 76
+    feats = synthetic.make_smooth_features(b, 256, hf, wf, 21 + v)
+    boxes = synthetic.make_boxes(n, hf * 4, wf * 4, 13 + v, r_min=8, r_max=60)
+    init = synthetic.make_circle_contours(boxes, v)
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
+    idx = (torch.arange(n) % b).float()
+    want = snake_ref.dance_deform(sd, feats, init, idx, [(hf * 4, wf * 4)] * b, whs)
+    d = snake.ContourDeformer(nets)
+    f = d.prepare_features(feats.to(device))
+    prev = init
+    for it in range(3):
+        one = d.evolve(it, *f, prev.to(device), idx.to(torch.int32).to(device), whs.to(device), use_att=it > 0,
+                       clip_first=False, clip_max=(0, 0))
+        assert_coords_close(one, want[it], "%d vertices, iteration %d" % (v, it))
+        prev = want[it]
