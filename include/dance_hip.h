@@ -555,7 +555,11 @@ typedef struct dance_snake_net16 {
 /* The 7 residual SnakeBlocks (res_* fields of the net) in one launch, v <= 256: state is the
  * (n, 8 slots) P16 block, slot 0 = head output (input), slots 1..7 receive the block outputs;
  * same results as 7 dance_conv16 calls (bit-identical up to 128 vertices; above, within 1e-5:
- * another MFMA shape, hence summation order), one kernel tail and launch gap instead of 7.  reference: _SnakeNet.forward snake_head.py:262-268. */
+ * another MFMA shape, hence summation order), one kernel tail and launch gap instead of 7.
+ * The ring runs ceil(v / 16) vertex tiles of 16 (at most one more): LDS images of 64, 96, 128, 160,
+ * 192, 224 or 256 columns; above 128 vertices (and for 97..128 with at most DANCE_STACK_SMALL_N
+ * contours) 8 waves per contour with the tiles split over two groups of waves, odd counts as k + (k - 1).
+ * reference: _SnakeNet.forward snake_head.py:262-268. */
 int dance_res_stack16(const dance_snake_net16 *net_host, void *state, int64_t stride, int64_t slot,
                       int n, int v, int mfma_terms, void *stream);
 
