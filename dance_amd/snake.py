@@ -242,7 +242,7 @@ class ContourDeformer:
         m = n - side_n
         dev = init_contours.device
         cur = torch.cuda.current_stream(dev)
-        if getattr(self, "_peel_side", None) is None:
+        if getattr(self, "_peel_side", None) is None or self._peel_side[0].device != dev:
             self._peel_side = (torch.cuda.Stream(dev),
                                ContourDeformer(self.nets, self._padding_name, self._deloc_name, self.individual_scale,
                                                self.attention, self.fused_head, self.precision))
