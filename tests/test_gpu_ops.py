@@ -1,0 +1,29 @@
+"""Host-side behaviour of dance_amd.ops around the resampler's status assert (the reference's
+`assert torch.all(edge_num_sum == p_num)`, snake_head.py:782) in its three modes."""
+import pytest
+import torch
+
+from dance_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lazy_status_check_raises_late(device, monkeypatch):
+    """DANCE_SYNC_CHECKS=lazy: the resampler's edge-count assert (snake_head.py:782) is not waited for;
+    flush_checks() -- or a later call once the status has arrived -- raises it.  "0" never raises."""
+    ok = torch.tensor([[10.0, 10.0, 50.0, 60.0]], device=device)
+    # a polygon of more edges than points to hand out cannot be resampled: status 1
+    bad = (torch.rand((1, 40, 2), generator=torch.Generator().manual_seed(3)) * 100).to(device)
+    with pytest.raises(AssertionError):
+        ops.uniform_upsample(bad, 16, kind=ops.POLY_RAW)
+    monkeypatch.setenv("DANCE_SYNC_CHECKS", "lazy")
+    ops.flush_checks()
+    ops.uniform_upsample(ok, 128, kind=ops.POLY_BOX)
+    ops.flush_checks()                                        # nothing wrong: nothing raised
+    ops.uniform_upsample(bad, 16, kind=ops.POLY_RAW)          # returns at once
+    with pytest.raises(AssertionError):
+        ops.flush_checks()
+    ops.flush_checks()                                        # the list is empty again
+    monkeypatch.setenv("DANCE_SYNC_CHECKS", "0")
+    ops.uniform_upsample(bad, 16, kind=ops.POLY_RAW)
+    ops.flush_checks()
