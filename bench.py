@@ -667,6 +667,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         total_flops = 2.0 * MACS_PER_VERTEX * v * n_total * ITERS     # whole job
         rt = 2 if v <= 64 else 4 if v <= 128 else 7 if v <= 224 else 8
+        if os.environ.get("DANCE_STACK_MID", "1") != "0":       # dance_res_stack16's image widths
+            rt = 3 if 64 < v <= 96 else 5 if 128 < v <= 160 else 6 if 160 < v <= 192 else rt
         # dance_res_stack16's dispatch: 8-wave kernel above 128 vertices and for few long rings
         stack_wide = v > 128 or (v > 96 and n_ev <= int(os.environ.get("DANCE_STACK_SMALL_N", "256")))
         stack13 = 192 < v <= 208 and os.environ.get("DANCE_STACK_ODD_SPLIT", "1") != "0"   # 13 vertex tiles as 7 + 6
@@ -703,6 +705,17 @@ def main():
                             + ("recorded inside the timed steps" if single_chunk and args.streams == 1 else
                                "recorded in an instrumented pass over the first %d contours after the timed "
                                "region" % n_ev) + "; executed = %d f16 MFMAs per product" % terms}
+            if side_n and stacked and not head_stack:
+                # the timed launch shares the CUs with the side stream's small kernels (the peeled
+                # remainder's chain); the same launch with the GPU to itself, from the instrumented
+                # single-stream pass over the same n_ev contours
+                alone_ms = sum(stage_avg["res%d" % i] for i in range(7))
+                alone_tflops = 2.0 * MACS_RES_BLOCK * v * n_ev * 7 / (alone_ms * 1e-3) / 1e12
+                roof["alone"] = {"avg_launch_ms": alone_ms, "achieved": alone_tflops,
+                                 "frac": alone_tflops / PEAK_F16_MFMA_TFLOPS,
+                                 "frac_executed": terms * alone_tflops / PEAK_F16_MFMA_TFLOPS,
+                                 "note": "the same launch without the side stream's kernels beside it "
+                                         "(instrumented pass after the timed region)"}
             if terms == 3:
                 roof["traffic"], roof["traffic_source"] = measured_traffic(
                     "k_head_stack16s" if head_stack else ("k_res_stack16w" if stack_wide else "k_res_stack16s")
