@@ -258,7 +258,7 @@ class RefineNet(_SnakeHeadBase):
     def _sample_octagons(self, pred_instances):
         """sample_octagons_fast (snake_head.py:844-863), incl. the in-place fit_to_box /
         clamp of the instances' extreme points."""
-        locs, idx = [], []
+        exts, idx = [], []
         for i, inst in enumerate(pred_instances):
             if inst.has("ext_points"):
                 h, w = inst.image_size
@@ -266,11 +266,13 @@ class RefineNet(_SnakeHeadBase):
                 ext = inst.ext_points.tensor
                 ext[..., 0].clamp_(min=0, max=w - 1)
                 ext[..., 1].clamp_(min=0, max=h - 1)
-                locs.append(self.get_octagon(ext, self.num_sampling)[0])
+                exts.append(ext)
                 idx.append(ext.new_empty(len(ext)).fill_(i))
-        if not locs:
-            return locs, idx
-        return torch.cat(locs, dim=0), torch.cat(idx)
+        if not exts:
+            return exts, idx
+        # every image's octagons in ONE resampler launch (and one status assert) instead of the
+        # reference's launch and synchronising assert per image; contours are independent
+        return self.get_octagon(torch.cat(exts, dim=0), self.num_sampling)[0], torch.cat(idx)
 
     # -- the path ------------------------------------------------------------------
     def _get_deformer(self):
