@@ -52,8 +52,9 @@ PEAK_HBM_GBPS = 8000.0
 WORKLOADS = {"cfg2": (16, 100, 128, "weak"), "cfg3": (32, 100, 128, "weak"), "cfg5": (256, 300, 256, "strong")}
 WORKLOAD_NAMES = {"cfg2": "BASELINE config 2", "cfg3": "BASELINE config 3", "cfg5": "BASELINE config 5"}
 # contours per kernel sequence above which a rank's batch is deformed in chunks (workspace:
-# 0.83 MB per 128-vertex contour, 1.65 MB per 256-vertex one)
-CHUNK_CAP = 9600
+# 0.83 MB per 128-vertex contour, 1.65 MB per 256-vertex one); a multiple of the 256 CUs, so that
+# every chunk but the last is whole rounds of workgroups (38 x 256)
+CHUNK_CAP = 9728
 
 
 def measured_traffic(kernel, workgroups):
