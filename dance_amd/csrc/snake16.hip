@@ -447,9 +447,10 @@ __device__ __forceinline__ void res_stack16_layers(const Stack16Args &a, long lo
                 // next block's input, in place (this lane owns these two half-words)
                 *reinterpret_cast<h4 *>(q) = hi;
                 *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
+                // written once, read once by the fusion kernel: non-temporal, the L2 keeps the weights
                 _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
-                *reinterpret_cast<h4 *>(d) = hi;
-                *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
+                __builtin_nontemporal_store(hi, reinterpret_cast<h4 *>(d));
+                __builtin_nontemporal_store(lo, reinterpret_cast<h4 *>(d + 128ll * v));
             }
         }
         __syncthreads();                    // image = block l + 1's input
@@ -546,9 +547,10 @@ __device__ __forceinline__ void res_stack16w_layers(const Stack16Args &a, _Float
                 }
                 *reinterpret_cast<h4 *>(q) = hi;
                 *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
+                // written once, read once by the fusion kernel: non-temporal, the L2 keeps the weights
                 _Float16 *d = yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf;
-                *reinterpret_cast<h4 *>(d) = hi;
-                *reinterpret_cast<h4 *>(d + 128ll * v) = lo;
+                __builtin_nontemporal_store(hi, reinterpret_cast<h4 *>(d));
+                __builtin_nontemporal_store(lo, reinterpret_cast<h4 *>(d + 128ll * v));
             }
         }
         __syncthreads();                    // image = block l + 1's input
