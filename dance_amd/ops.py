@@ -36,13 +36,14 @@ def sync_checks():
       "1" (default): as the reference, the host waits for the status right away;
       "lazy": the status goes to pinned host memory asynchronously and is asserted by a later call
               (or by flush_checks()) once its copy has completed -- same assert, a forward or two
-              late, and the host keeps queueing work meanwhile (Dsnake module at 32 x 100: 226.8k ->
-              241k contours/s, DESIGN 5a);
+              late, and the host keeps queueing work meanwhile (Dsnake module at 32 x 100: 224k ->
+              242k contours/s, DESIGN 5a);
       "0": never looked at."""
     return os.environ.get("DANCE_SYNC_CHECKS", "1")
 
 
-_PENDING = []       # (pinned bool tensor, event) of lazy checks not yet looked at
+_PENDING = []       # (pinned bool element, event) of lazy checks not yet looked at
+_PINNED, _PINNED_NEXT, _PINNED_SLOTS = None, 0, 64
 
 
 def _assert_status(status_list):
@@ -55,7 +56,13 @@ def _assert_status(status_list):
     if mode != "lazy":
         assert not bool(bad), "uniform_upsample: edge counts do not sum to p_num"
         return
-    host = torch.empty((), dtype=torch.bool, pin_memory=True)
+    global _PINNED, _PINNED_NEXT
+    if _PINNED is None:
+        _PINNED = torch.zeros((_PINNED_SLOTS,), dtype=torch.bool, pin_memory=True)   # one allocation, reused
+    if len(_PENDING) >= _PINNED_SLOTS:
+        flush_checks(wait=True)                  # every slot taken: look at them all before reusing one
+    host = _PINNED[_PINNED_NEXT % _PINNED_SLOTS]
+    _PINNED_NEXT += 1
     host.copy_(bad, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
