@@ -237,6 +237,9 @@ class ContourDeformer:
         return n % cus
 
     def _deform_peeled(self, features, init_contours, image_idx, image_sizes, whs, layout, stage_events, side_n):
+        """deform() with the last `side_n` contours as their own kernel chain on a side stream (forked
+        after the layout pass, joined before returning); both chains write into the same output
+        tensors, `stage_events` time the main stream's launches."""
         feat_att = self.prepare_features(features) if layout == "nchw" else features
         n, v = init_contours.shape[:2]
         m = n - side_n
