@@ -282,13 +282,16 @@ extern "C" int dance_tail16(const void *p1, int64_t p1_stride, int64_t p1_slot_s
     a.parts = parts; a.wg = wg; a.pb = pred0_bias; a.w1 = (const h8 *)w1_16; a.b1s = b1_scaled;
     a.winv1 = w1_inv_scale; a.w3 = w3; a.b3 = b3; a.loc = loc; a.whs = whs; a.att = att; a.out = out;
     a.v = v; a.clip_first = clip_first; a.clip_x = clip_x_max; a.clip_y = clip_y_max;
-    // one contour per workgroup.  DANCE_TAIL16_GROUP=4: four per workgroup share every load of the
-    // row-constant matrix -- ahead at 1024+ contours when this kernel was written, behind since the
-    // library is built without packed fp32 forms (same box: 0.0816 vs 0.0745 ms at 1600 x 128, 0.153 vs
-    // 0.130 ms at 3200; equal at 196 vertices)
-    const char *e = getenv("DANCE_TAIL16_GROUP");           // read per call: the tests run both
-    const int group = e && *e ? atoi(e) : 1;
+    // contours per workgroup (they share every load of the row-constant matrix): two from 1024 contours
+    // on (tail 0.0626 -> 0.0576 ms at 1536 x 128, 0.132 -> 0.122 ms at 3072), one below; four was ahead
+    // when this kernel was written and is behind since the library is built without packed fp32 forms
+    // (0.0816 vs 0.0745 ms at 1600 x 128), three is behind too.  DANCE_TAIL16_GROUP=1|2|4 fixes it
+    // (read per call: the tests run all three).
+    const char *e = getenv("DANCE_TAIL16_GROUP");
+    const int group = e && *e ? atoi(e) : (n >= 1024 ? 2 : 1);
     if (group >= 4)
         return launch_tail_rt<4>(a, n, mfma_terms, (hipStream_t)stream);
+    if (group >= 2)
+        return launch_tail_rt<2>(a, n, mfma_terms, (hipStream_t)stream);
     return launch_tail_rt<1>(a, n, mfma_terms, (hipStream_t)stream);
 }
