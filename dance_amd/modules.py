@@ -307,11 +307,19 @@ class RefineNet(_SnakeHeadBase):
         """The `snake_deformation` scope (snake_head.py:1822-1862): per-iteration contours."""
         with timer.env("snake_feat_prep"):
             d, nhwc, att = self._features(features)
-        # halves of the contours on two HIP streams (bit-identical results; one half's kernel tails and
-        # launch gaps overlap the other half's kernels: +3..4 % at 1600+ contours) from 1024 contours
-        # on, never under stream capture; DANCE_STREAMS=<k> fixes the count
+        # a batch that is not whole rounds of workgroups: deform() itself peels the remainder off to a
+        # side stream (279.0k vs 276.0k contours/s with an even split at 1600, same box).  Whole rounds,
+        # from 1024 contours on: halves on two HIP streams (one half's kernel tails and launch gaps overlap
+        # the other half's kernels, +0.3..0.5 %).  Bit-identical either way, never under stream capture;
+        # DANCE_STREAMS=<k> fixes the count
         env = os.environ.get("DANCE_STREAMS")
-        streams = int(env) if env else (2 if len(locations) >= 1024 and not torch.cuda.is_current_stream_capturing() else 1)
+        if env:
+            streams = int(env)
+        elif torch.cuda.is_current_stream_capturing() or len(locations) < 1024 or \
+                (image_idx is not None and d.peel_count(len(locations), locations.device)):
+            streams = 1
+        else:
+            streams = 2
         with timer.env("snake_deformation"):
             return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc", streams=streams)
 

@@ -135,3 +135,38 @@ def test_tail16_group_sizes_agree(device, monkeypatch):
     _, small = _fused(net.struct16, state[-k:].contiguous(), loc[-k:].contiguous(), whs[-k:].contiguous(),
                       att[-k:].contiguous(), k, v, 3, False)
     assert torch.equal(outs["4"][-k:], small)
+
+
+
+@pytest.mark.parametrize("v", [128, 196])
+def test_fuse_raw_tail_reruns_are_bit_identical_with_late_workgroups(device, v):
+    """3200 contours = more workgroups than the chip holds at once, so many start while others
+    are in their MFMA phase.  A GEMV the compiler had paired into v_pk_fma_f32 gave run-to-run
+    different row constants in exactly those workgroups (tail16.hip, fma1); reruns must agree to
+    the bit, and a contour's result must not depend on where in the launch it sits."""
+    cfg, sd, _ = dance_state_dict(34, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer0."), device)
+    n = 3200
+    x, state, loc, whs, att = _inputs(n, v, device, 2)
+    outs = [_fused(net.struct16, state, loc, whs, att, n, v, 3, False)[1] for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    k = 640                                                 # the last 640 contours alone, all started early
+    _, alone = _fused(net.struct16, state[-k:].contiguous(), loc[-k:].contiguous(), whs[-k:].contiguous(),
+                      att[-k:].contiguous(), k, v, 3, False)
+    assert torch.equal(outs[0][-k:], alone)
+
+
+@pytest.mark.parametrize("v", [40, 128, 196, 256])
+def test_fuse_raw_four_wave_split_equals_eight_wave(device, v, monkeypatch):
+    """DANCE_FUSE16_WAVES=4: the 512 outputs as two 4-wave workgroups (64-channel chunks staged by
+    LDS-direct loads).  Same products in the same order per output element: identical bits."""
+    cfg, sd, _ = dance_state_dict(35, 128)
+    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer2."), device)
+    n = 300
+    x, state, loc, whs, att = _inputs(n, v, device, 11)
+    res = {}
+    for waves in ("8", "4"):
+        monkeypatch.setenv("DANCE_FUSE16_WAVES", waves)
+        res[waves] = [_fused(net.struct16, state, loc, whs, att, n, v, terms, False) for terms in (3, 1)]
+    for a, b in zip(res["8"], res["4"]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
