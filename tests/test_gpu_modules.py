@@ -59,6 +59,47 @@ def test_refinenet_batched(device):
     assert res[0].pred_path.shape == (3, 4, 196, 2)
 
 
+def test_refinenet_batched_many_instances_stream_policies(device, monkeypatch):
+    """The batched module path at sizes where its stream policy switches (modules.RefineNet.deform):
+    6 x 100 contours (one stream, 88 peeled to the side stream on a 256-CU GPU), 8 x 128 = 1024 (whole
+    rounds: two streams) -- each against DANCE_STREAMS=1 with DANCE_PEEL=0, bit for bit, box and octagon
+    initial contours."""
+    g, cfg, sd, feats, image_idx, sizes = dance_case_inputs("smooth_batched_box_v196")
+    cfg.vis_path = True
+    for initial in ("box", "octagon"):
+        cfg.initial = initial
+        net = _module(cfg, sd, device)
+        for b, per in ((6, 100), (8, 128)):
+            fb = feats[:1].repeat(b, 1, 1, 1).to(device)
+            fb = fb + 0.01 * torch.arange(b, device=device).view(b, 1, 1, 1)
+            h, w = sizes[0]
+            boxes = synthetic.make_boxes(b * per, h, w, 31 + b).view(b, per, 4).to(device)
+
+            def run():
+                insts = []
+                for i in range(b):
+                    kw = {}
+                    if initial == "octagon":
+                        bx = boxes[i]
+                        cx, cy = (bx[:, 0] + bx[:, 2]) / 2, (bx[:, 1] + bx[:, 3]) / 2
+                        ext = torch.stack([torch.stack([cx, bx[:, 1]], 1), torch.stack([bx[:, 0], cy], 1),
+                                           torch.stack([cx, bx[:, 3]], 1), torch.stack([bx[:, 2], cy], 1)], 1)
+                        kw["ext_points"] = ExtremePoints(ext.clone())
+                    insts.append(FakeInstances((h, w), pred_boxes=FakeBoxes(boxes[i].clone()), **kw))
+                with torch.no_grad():
+                    res, _ = net(fb, insts, None)
+                return torch.cat([r.pred_polys.tensor for r in res])
+
+            monkeypatch.delenv("DANCE_STREAMS", raising=False)
+            monkeypatch.delenv("DANCE_PEEL", raising=False)
+            got = run()
+            monkeypatch.setenv("DANCE_STREAMS", "1")
+            monkeypatch.setenv("DANCE_PEEL", "0")
+            want = run()
+            assert got.shape == (b * per, 196, 2)
+            assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (initial, b, per)
+
+
 def test_bottom_out_channels_last_feeds_the_gather(device):
     """with bottom_out in place (NUM_CONVS=2) the torch convs run channels_last and their
     output is consumed without a layout pass; result = the oracle on the same features."""
