@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
     auto nohook = [](int) __attribute__((always_inline)) {};
     for (int c0 = 0; c0 < a.c; c0 += 64) {
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
         for (int s = vs; s < v; s += 16) {
 #pragma clang fp contract(off)
             const float w0 = tw[s * 4 + 0], w1 = tw[s * 4 + 1], w2 = tw[s * 4 + 2], w3 = tw[s * 4 + 3];
