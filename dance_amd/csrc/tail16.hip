@@ -283,12 +283,13 @@ extern "C" int dance_tail16(const void *p1, int64_t p1_stride, int64_t p1_slot_s
     a.winv1 = w1_inv_scale; a.w3 = w3; a.b3 = b3; a.loc = loc; a.whs = whs; a.att = att; a.out = out;
     a.v = v; a.clip_first = clip_first; a.clip_x = clip_x_max; a.clip_y = clip_y_max;
     // contours per workgroup (they share every load of the row-constant matrix): two from 1024 contours
-    // on (tail 0.0626 -> 0.0576 ms at 1536 x 128, 0.132 -> 0.122 ms at 3072), one below; four was ahead
-    // when this kernel was written and is behind since the library is built without packed fp32 forms
-    // (0.0816 vs 0.0745 ms at 1600 x 128), three is behind too.  DANCE_TAIL16_GROUP=1|2|4 fixes it
-    // (read per call: the tests run all three).
+    // on for rings up to 128 vertices (tail 0.0626 -> 0.0576 ms at 1536 x 128, 0.132 -> 0.122 ms at
+    // 3072; longer rings: behind, 0.127 vs 0.121 ms at 1536 x 196, 0.142 vs 0.138 ms at 256), else one.
+    // Four was ahead when this kernel was written and is behind since the library is built without
+    // packed fp32 forms (0.0816 vs 0.0745 ms at 1600 x 128), three is behind too.
+    // DANCE_TAIL16_GROUP=1|2|4 fixes it (read per call: the tests run all three).
     const char *e = getenv("DANCE_TAIL16_GROUP");
-    const int group = e && *e ? atoi(e) : (n >= 1024 ? 2 : 1);
+    const int group = e && *e ? atoi(e) : (n >= 1024 && v <= 128 ? 2 : 1);
     if (group >= 4)
         return launch_tail_rt<4>(a, n, mfma_terms, (hipStream_t)stream);
     if (group >= 2)
