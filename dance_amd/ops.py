@@ -42,19 +42,17 @@ def sync_checks():
     return os.environ.get("DANCE_SYNC_CHECKS", "1")
 
 
-_PENDING = []       # (pinned bool element, event) of lazy checks not yet looked at
+_PENDING = []       # (pinned bool element, event, message) of lazy checks not yet looked at
 _PINNED, _PINNED_NEXT, _PINNED_SLOTS = None, 0, 64
 
 
-def _assert_status(status_list):
-    """Assert, in the mode sync_checks() names, that no status tensor of the list is set."""
+def assert_not(bad, message):
+    """`assert not bad` for a boolean device scalar, in the mode sync_checks() names."""
     mode = sync_checks()
-    status_list = [s for s in status_list if s.numel()]
-    if mode == "0" or not status_list or torch.cuda.is_current_stream_capturing():
+    if mode == "0" or torch.cuda.is_current_stream_capturing():
         return
-    bad = torch.stack([s.any() for s in status_list]).any()
     if mode != "lazy":
-        assert not bool(bad), "uniform_upsample: edge counts do not sum to p_num"
+        assert not bool(bad), message
         return
     global _PINNED, _PINNED_NEXT
     if _PINNED is None:
@@ -66,23 +64,32 @@ def _assert_status(status_list):
     host.copy_(bad, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _PENDING.append((host, ev))
+    _PENDING.append((host, ev, message))
     flush_checks(wait=False)
+
+
+def _assert_status(status_list):
+    """The resampler's edge-count assert over a list of status tensors."""
+    status_list = [s for s in status_list if s.numel()]
+    if sync_checks() == "0" or not status_list:
+        return
+    assert_not(torch.stack([s.any() for s in status_list]).any(), "uniform_upsample: edge counts do not sum to p_num")
 
 
 def flush_checks(wait=True):
     """Look at the lazy checks whose status has arrived (wait=True: wait for all of them); a check
     that fails is reported once."""
-    keep, failed = [], False
-    for host, ev in _PENDING:
+    keep, failed = [], None
+    for host, ev, message in _PENDING:
         if wait:
             ev.synchronize()
         if wait or ev.query():
-            failed = failed or bool(host)
+            if bool(host) and failed is None:
+                failed = message
         else:
-            keep.append((host, ev))
+            keep.append((host, ev, message))
     _PENDING[:] = keep
-    assert not failed, "uniform_upsample: edge counts do not sum to p_num"
+    assert failed is None, failed
 
 
 def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True, deferred=None):

@@ -48,8 +48,13 @@ class PolygonPoints(_PointSet):
     def clip(self, box_size):
         """pointset.py:247-251, the finite check included: a collapsed contour (`derange` divides by
         max - min with no epsilon, snake_head.py:1588-1593) is NaN there and here, and the reference
-        raises at this point instead of rasterising garbage (one host sync, as in the reference)."""
-        assert torch.isfinite(self.tensor).all(), "Polygon tensor contains infinite or NaN!"
+        raises at this point instead of rasterising garbage (one host sync, as in the reference;
+        DANCE_SYNC_CHECKS=lazy raises it from a later call instead)."""
+        if self.tensor.is_cuda:
+            from . import ops                    # the assert in the mode DANCE_SYNC_CHECKS names (ops.sync_checks)
+            ops.assert_not(~torch.isfinite(self.tensor).all(), "Polygon tensor contains infinite or NaN!")
+        else:
+            assert torch.isfinite(self.tensor).all(), "Polygon tensor contains infinite or NaN!"
         h, w = box_size
         self.tensor[:, :, 0].clamp_(min=0, max=w)
         self.tensor[:, :, 1].clamp_(min=0, max=h)

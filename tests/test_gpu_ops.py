@@ -27,3 +27,24 @@ def test_lazy_status_check_raises_late(device, monkeypatch):
     monkeypatch.setenv("DANCE_SYNC_CHECKS", "0")
     ops.uniform_upsample(bad, 16, kind=ops.POLY_RAW)
     ops.flush_checks()
+
+
+def test_polygon_clip_finite_check_modes(device, monkeypatch):
+    """PolygonPoints.clip's finite assert (pointset.py:247-251) in the three DANCE_SYNC_CHECKS modes."""
+    from dance_amd.structures import PolygonPoints
+    good = torch.rand((3, 128, 2), device=device) * 50
+    bad = good.clone()
+    bad[1, 7, 0] = float("nan")
+    PolygonPoints(good.clone()).clip((40, 40))
+    with pytest.raises(AssertionError):
+        PolygonPoints(bad.clone()).clip((40, 40))
+    monkeypatch.setenv("DANCE_SYNC_CHECKS", "lazy")
+    ops.flush_checks()
+    p = PolygonPoints(bad.clone())
+    p.clip((40, 40))                                           # returns; the clamp has run
+    assert float(p.tensor[0].max()) <= 40.0
+    with pytest.raises(AssertionError, match="Polygon tensor"):
+        ops.flush_checks()
+    monkeypatch.setenv("DANCE_SYNC_CHECKS", "0")
+    PolygonPoints(bad.clone()).clip((40, 40))
+    ops.flush_checks()
