@@ -159,6 +159,13 @@ def _reference_init(module):
                 nn.init.constant_(m.bias, 0)
 
 
+def _image_index(tensors):
+    """(sum of len(t),) image number of every row, in the tensors' dtype: one arange and one cat instead of
+    a fill launch per image (the reference: `b.new_empty(len(b)).fill_(i)` per image)."""
+    ar = torch.arange(len(tensors), dtype=tensors[0].dtype, device=tensors[0].device)
+    return torch.cat([ar[i:i + 1].expand(len(t)) for i, t in enumerate(tensors)])
+
+
 def _image_slices(counts):
     """contiguous per-image ranges of a batch laid out image by image"""
     out, start = [], 0
@@ -252,8 +259,7 @@ class RefineNet(_SnakeHeadBase):
         allb = torch.cat(boxes, dim=0) if len(boxes) > 1 else boxes[0]
         locs, _ = ops.uniform_upsample(allb, self.num_sampling, kind=ops.POLY_BOX) if len(allb) else \
             (torch.zeros([0, self.num_sampling, 2], device=allb.device), None)
-        idx = torch.cat([b.new_empty(len(b)).fill_(i) for i, b in enumerate(boxes)])
-        return locs, idx
+        return locs, _image_index(boxes)
 
     def _sample_octagons(self, pred_instances):
         """sample_octagons_fast (snake_head.py:844-863), incl. the in-place fit_to_box /
@@ -490,7 +496,7 @@ class DsnakeHead(_SnakeHeadBase):
         if len(allb) == 0:
             return pred_instances, {}
         init_locations, _ = ops.uniform_upsample(allb, 40, kind=ops.POLY_QUAD)   # :438-451
-        image_idx = torch.cat([b.new_empty(len(b)).fill_(i) for i, b in enumerate(boxes)])
+        image_idx = _image_index(boxes)
         idx = image_idx.to(torch.int32)
         d = self._get_deformer()
         nhwc = self._bottom(features, 0)
