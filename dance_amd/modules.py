@@ -472,9 +472,11 @@ class DsnakeHead(_SnakeHeadBase):
         status goes to `deferred`)."""
         pred_exts = self.init_stage(d, nhwc, init_locations, idx)
         h, w = nhwc.shape[1] * 4, nhwc.shape[2] * 4
-        exts = pred_exts.clone()
-        exts[..., 0] = torch.clamp(exts[..., 0], min=0, max=w - 1)               # :800-805
-        exts[..., 1] = torch.clamp(exts[..., 1], min=0, max=h - 1)
+        key = (h, w, pred_exts.device)
+        if getattr(self, "_clamp_hi", None) is None or self._clamp_hi[0] != key:
+            self._clamp_hi = (key, torch.zeros(2, device=pred_exts.device),
+                              torch.tensor([w - 1.0, h - 1.0], device=pred_exts.device))
+        exts = torch.clamp(pred_exts, min=self._clamp_hi[1], max=self._clamp_hi[2])   # :800-805, one launch
         if gt_mask is not None:
             exts = torch.where(gt_mask[:, None, None], gt_exts, exts)
         locations, _ = ops.uniform_upsample(exts.contiguous(), self.num_sampling, kind=ops.POLY_OCTAGON,
