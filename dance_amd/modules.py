@@ -497,7 +497,8 @@ class DsnakeHead(_SnakeHeadBase):
         allb = torch.cat(boxes, dim=0)
         if len(allb) == 0:
             return pred_instances, {}
-        init_locations, _ = ops.uniform_upsample(allb, 40, kind=ops.POLY_QUAD)   # :438-451
+        deferred = []                                # resampler status tensors: one assert (one sync) at the end
+        init_locations, _ = ops.uniform_upsample(allb, 40, kind=ops.POLY_QUAD, deferred=deferred)   # :438-451
         image_idx = _image_index(boxes)
         idx = image_idx.to(torch.int32)
         d = self._get_deformer()
@@ -518,7 +519,6 @@ class DsnakeHead(_SnakeHeadBase):
         # k HIP streams (bit-identical).  Not the default here: measured 14.97 vs 15.08 ms per forward
         # at 32 x 100 (+0.7 %), and slower with NUM_CONVS = 2 (the feature prep stays on one stream)
         k = int(os.environ.get("DANCE_STREAMS", "1"))
-        deferred = []
         if k <= 1:
             pred_exts, exts, locations, preds = self._chain(d, nhwc, init_locations, idx, gt_exts, gt_mask, deferred)
         else:
