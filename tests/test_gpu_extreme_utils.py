@@ -120,7 +120,8 @@ def test_fused_resampler_golden_bit_exact(device):
     assert torch.equal(pts.cpu(), g["octagon_p128_points"]) and torch.equal(start.cpu(), g["octagon_p128_start"])
 
 
-def test_fused_resampler_builders_and_large(device):
+def test_fused_resampler_builders_and_large(device, monkeypatch):
+    monkeypatch.delenv("DANCE_SYNC_CHECKS", raising=False)    # the immediate assert is what is tested
     from dance_amd import synthetic
     from oracle import snake_ref
     boxes = synthetic.make_boxes(3000, 800, 1216, seed=5)

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_lazy_status_check_raises_late(device, monkeypatch):
     """DANCE_SYNC_CHECKS=lazy: the resampler's edge-count assert (snake_head.py:782) is not waited for;
     flush_checks() -- or a later call once the status has arrived -- raises it.  "0" never raises."""
+    monkeypatch.delenv("DANCE_SYNC_CHECKS", raising=False)
     ok = torch.tensor([[10.0, 10.0, 50.0, 60.0]], device=device)
     # a polygon of more edges than points to hand out cannot be resampled: status 1
     bad = (torch.rand((1, 40, 2), generator=torch.Generator().manual_seed(3)) * 100).to(device)
@@ -32,6 +33,7 @@ def test_lazy_status_check_raises_late(device, monkeypatch):
 def test_polygon_clip_finite_check_modes(device, monkeypatch):
     """PolygonPoints.clip's finite assert (pointset.py:247-251) in the three DANCE_SYNC_CHECKS modes."""
     from dance_amd.structures import PolygonPoints
+    monkeypatch.delenv("DANCE_SYNC_CHECKS", raising=False)
     good = torch.rand((3, 128, 2), device=device) * 50
     bad = good.clone()
     bad[1, 7, 0] = float("nan")
