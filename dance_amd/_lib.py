@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -100,6 +100,7 @@ SIGNATURES = {
     "dance_segment_matching": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_multisegment_matching": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_uniform_upsample": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P]),
+    "dance_octagon_upsample": (c_int, [P, c_int64, c_int64, P, P, c_int, c_float, c_float, c_int, c_int, P, P, P, P, P]),
     "dance_nchw_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_gather_features": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, P]),

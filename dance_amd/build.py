@@ -67,6 +67,50 @@ def _compile(cmd):
         raise subprocess.CalledProcessError(r.returncode, cmd)
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+PACKED_FP32 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")
+
+
+def device_isa_counts(so_path=OUT, patterns=PACKED_FP32 + ("v_mfma_f32",)):
+    """Disassemble every gfx950 code object bundled in `so_path` and count the instructions whose
+    mnemonic starts with one of `patterns`.  The guard behind NOPK: the flag is a compiler
+    feature switch that a later toolchain may stop honouring (its host-pass warning is filtered
+    out in _compile), so the ISA itself is what build() and tests/test_abi.py look at."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="dance_isa_")
+    try:
+        so = os.path.join(tmp, os.path.basename(so_path))
+        shutil.copy(so_path, so)            # llvm-objdump --offloading extracts next to its input
+        subprocess.check_call([OBJDUMP, "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
+        if not objs:
+            raise RuntimeError("no gfx950 code object found in %s" % so_path)
+        counts = {p: 0 for p in patterns}
+        for f in objs:
+            text = subprocess.run([OBJDUMP, "-d", "--mcpu=" + ARCH, os.path.join(tmp, f)], check=True,
+                                  stdout=subprocess.PIPE, text=True).stdout
+            for line in text.splitlines():
+                parts = line.split()
+                if parts:
+                    for p in patterns:
+                        if parts[0].startswith(p):
+                            counts[p] += 1
+        counts["code_objects"] = len(objs)
+        return counts
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def check_no_packed_fp32(so_path=OUT):
+    c = device_isa_counts(so_path)
+    bad = {p: c[p] for p in PACKED_FP32 if c[p]}
+    if bad:
+        raise RuntimeError("libdance_hip.so holds packed fp32 VALU instructions %r: the compiler no longer honours "
+                           "-packed-fp32-ops (see NOPK in dance_amd/build.py, DESIGN.md 5a)" % bad)
+    return c
+
+
 def build(force=False, keep_asm=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
@@ -92,6 +136,7 @@ def build(force=False, keep_asm=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        check_no_packed_fp32(OUT)           # fail the build, not a later run
     return OUT
 
 

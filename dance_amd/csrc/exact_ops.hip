@@ -18,7 +18,7 @@ char *error_buffer() { return g_error; }
 using dance::ceil_div;
 using dance::launch_check;
 
-extern "C" int dance_abi_version(void) { return 10; }
+extern "C" int dance_abi_version(void) { return 11; }
 extern "C" const char *dance_last_error(void) { return dance::error_buffer(); }
 
 extern "C" int dance_device_info(int *cu_count_host, int *lds_bytes_host)
@@ -529,6 +529,13 @@ extern "C" int dance_nms_sorted_plain_static(const float *boxes_sorted, int n, f
     unsigned long long *ws = nullptr;
     if (int rc = nms_static_scratch(&ws, __func__))
         return rc;
+    if (stream != nullptr) {        // the array is the CURRENT device's: a stream of another device would get the wrong GPU's
+        int cur = -1, sdev = -1;
+        if (hipGetDevice(&cur) == hipSuccess && hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess &&
+            sdev != cur)
+            return dance::fail((int)hipErrorInvalidDevice, __func__,
+                               "the stream belongs to another device than the current one");
+    }
     // nothing in the scratch has to start at zero: k_nms_mask writes every word the sweep reads
     // (diagonal and right of it) and the sweep clears its removal words itself
     return nms_sorted_impl(boxes_sorted, n, thresh, 0, (uint64_t *)ws, keep, count, stream);
@@ -595,10 +602,22 @@ extern "C" int dance_contour_upsample_2x(const float *loc, float *out, int n, in
 // ------------------------------------------------------------------------------------
 #define RS_MAX_E 64
 
+// kind OCTAGON only: what DsnakeHead.forward does to the init snake's extreme points before
+// get_octagon (dsnake_head.py:800-817) -- clamp to the image, take the ground-truth points where
+// they are given -- done while the points are loaded, and the points actually used written out.
+struct RsExtremes {
+    const float *override_pts;           // (n, 4, 2) or null
+    const unsigned char *override_mask;  // (n) non-zero: take override_pts[poly]
+    float *used;                         // (n, 4, 2) out or null
+    float x_max, y_max;                  // clamp to [0, x_max] x [0, y_max] ...
+    int clamp;                           // ... when non-zero
+    long long poly_stride, point_stride; // floats between instances / between the 4 points in src
+};
+
 __global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *__restrict__ src,
                                                          int E, int p_num, float *__restrict__ out,
                                                          long long *__restrict__ start_out,
-                                                         int *__restrict__ status)
+                                                         int *__restrict__ status, RsExtremes x)
 {
     __shared__ float px[RS_MAX_E], py[RS_MAX_E], len[RS_MAX_E];
     __shared__ long long cnt[RS_MAX_E], start[RS_MAX_E];
@@ -639,9 +658,30 @@ __global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *
     } else {
         // 12-gon from extreme points t,l,b,r: snake_head.py:800-830
         if (lane < 12) {
-            const float *e = src + poly * 8;
-            const float tx = e[0], ty = e[1], lx = e[2], ly = e[3];
-            const float bx = e[4], by = e[5], rx = e[6], ry = e[7];
+            const float *e = src + poly * x.poly_stride;
+            float ev[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float c = e[(k >> 1) * x.point_stride + (k & 1)];
+                if (x.clamp) {                              // tensor.clamp_(min=0, max=..): NaN stays NaN
+                    const float hi = (k & 1) ? x.y_max : x.x_max;
+                    c = c < 0.0f ? 0.0f : (c > hi ? hi : c);
+                }
+                ev[k] = c;
+            }
+            if (x.override_pts != nullptr && x.override_mask[poly]) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    ev[k] = x.override_pts[poly * 8 + k];
+            }
+            if (x.used != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)                 // (no dynamic register-array index)
+                    if (lane == k)
+                        x.used[poly * 8 + k] = ev[k];
+            }
+            const float tx = ev[0], ty = ev[1], lx = ev[2], ly = ev[3];
+            const float bx = ev[4], by = ev[5], rx = ev[6], ry = ev[7];
             const float w8 = (rx - lx) / 8.0f, h8 = (by - ty) / 8.0f;
             float x, y;
             switch (lane) {
@@ -758,7 +798,26 @@ extern "C" int dance_uniform_upsample(int kind, const float *src, int n, int e, 
     if (n == 0)
         return 0;
     DANCE_REQUIRE(src && out && status);
+    RsExtremes x = {nullptr, nullptr, nullptr, 0.0f, 0.0f, 0, 8, 2};
     hipLaunchKernelGGL(k_uniform_upsample, dim3(n), dim3(64), 0, (hipStream_t)stream, kind, src, e,
-                       p_num, out, (long long *)edge_start_idx, (int *)status);
+                       p_num, out, (long long *)edge_start_idx, (int *)status, x);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_octagon_upsample(const float *ext_points, int64_t poly_stride, int64_t point_stride,
+                                      const float *override_pts,
+                                      const uint8_t *override_mask, int clamp, float x_max, float y_max,
+                                      int n, int p_num, float *out, float *ext_used,
+                                      int64_t *edge_start_idx, int32_t *status, void *stream)
+{
+    DANCE_REQUIRE(n >= 0 && p_num >= 1 && p_num <= 4096);
+    if (n == 0)
+        return 0;
+    DANCE_REQUIRE(ext_points && out && status);
+    DANCE_REQUIRE((override_pts == nullptr) == (override_mask == nullptr));
+    DANCE_REQUIRE(point_stride >= 2 && poly_stride >= 2);
+    RsExtremes x = {override_pts, override_mask, ext_used, x_max, y_max, clamp, poly_stride, point_stride};
+    hipLaunchKernelGGL(k_uniform_upsample, dim3(n), dim3(64), 0, (hipStream_t)stream, DANCE_POLY_OCTAGON,
+                       ext_points, 12, p_num, out, (long long *)edge_start_idx, (int *)status, x);
     return launch_check(__func__);
 }

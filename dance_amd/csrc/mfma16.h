@@ -359,7 +359,8 @@ __device__ __forceinline__ void stage_dma(int jlo, int jhi, const char *src, uns
             if (RT % 2 == 0 || col0 + lane < RT * 32)
                 // nt: the staged activations are read once; without the hint they displace the
                 // weights every workgroup re-reads from L2 (fusion 0.464 -> 0.452 ms at 1536 contours)
-                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(g), "s"(l) : "memory");
+                // (m0 is clobbered: the compiler must not keep a value of its own in it across the asm)
+                asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(g), "s"(l) : "memory", "m0");
         }
 }
 

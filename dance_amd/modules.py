@@ -472,15 +472,11 @@ class DsnakeHead(_SnakeHeadBase):
         status goes to `deferred`)."""
         pred_exts = self.init_stage(d, nhwc, init_locations, idx)
         h, w = nhwc.shape[1] * 4, nhwc.shape[2] * 4
-        key = (h, w, pred_exts.device)
-        if getattr(self, "_clamp_hi", None) is None or self._clamp_hi[0] != key:
-            self._clamp_hi = (key, torch.zeros(2, device=pred_exts.device),
-                              torch.tensor([w - 1.0, h - 1.0], device=pred_exts.device))
-        exts = torch.clamp(pred_exts, min=self._clamp_hi[1], max=self._clamp_hi[2])   # :800-805, one launch
-        if gt_mask is not None:
-            exts = torch.where(gt_mask[:, None, None], gt_exts, exts)
-        locations, _ = ops.uniform_upsample(exts.contiguous(), self.num_sampling, kind=ops.POLY_OCTAGON,
-                                            deferred=deferred)
+        # clamp to the image (:800-805), GT points where given (:811-817) and get_octagon (:808-810)
+        # in one library launch: no torch elementwise kernel runs inside a forked stream
+        locations, exts, _ = ops.octagon_upsample(pred_exts, self.num_sampling, clamp_max=(w - 1.0, h - 1.0),
+                                                  override=gt_exts if gt_mask is not None else None,
+                                                  override_mask=gt_mask, deferred=deferred)
         preds, cur = [], locations
         for i in range(len(self.num_iter)):
             cur = d.evolve(1 + i, nhwc, None, cur, idx, None, use_att=False, clip_first=False,

@@ -42,29 +42,33 @@ def sync_checks():
     return os.environ.get("DANCE_SYNC_CHECKS", "1")
 
 
-_PENDING = []       # (pinned bool element, event, message) of lazy checks not yet looked at
-_PINNED, _PINNED_NEXT, _PINNED_SLOTS = None, 0, 64
+_PENDING = []       # (pinned slot index, event, message) of lazy checks not yet looked at
+_PINNED, _PINNED_SLOTS = None, 64
+_FREE_SLOTS = list(range(_PINNED_SLOTS))      # a slot returns here when its entry is flushed
 
 
 def assert_not(bad, message):
     """`assert not bad` for a boolean device scalar, in the mode sync_checks() names."""
     mode = sync_checks()
+    # under HIP-graph capture no status can reach the host: the check is skipped there and the
+    # graphed caller looks at its outputs after the replay instead (dance_amd/graph.py)
     if mode == "0" or torch.cuda.is_current_stream_capturing():
         return
     if mode != "lazy":
         assert not bool(bad), message
         return
-    global _PINNED, _PINNED_NEXT
+    global _PINNED
     if _PINNED is None:
         _PINNED = torch.zeros((_PINNED_SLOTS,), dtype=torch.bool, pin_memory=True)   # one allocation, reused
-    if len(_PENDING) >= _PINNED_SLOTS:
-        flush_checks(wait=True)                  # every slot taken: look at them all before reusing one
-    host = _PINNED[_PINNED_NEXT % _PINNED_SLOTS]
-    _PINNED_NEXT += 1
-    host.copy_(bad, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    _PENDING.append((host, ev, message))
+    if not _FREE_SLOTS:
+        flush_checks(wait=True)                  # every slot taken: look at them all, which frees them
+    slot = _FREE_SLOTS.pop()
+    # copy and event on the stream `bad` was produced on: its device's current stream
+    with torch.cuda.device(bad.device):
+        _PINNED[slot].copy_(bad, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    _PENDING.append((slot, ev, message))
     flush_checks(wait=False)
 
 
@@ -80,14 +84,15 @@ def flush_checks(wait=True):
     """Look at the lazy checks whose status has arrived (wait=True: wait for all of them); a check
     that fails is reported once."""
     keep, failed = [], None
-    for host, ev, message in _PENDING:
+    for slot, ev, message in _PENDING:
         if wait:
             ev.synchronize()
         if wait or ev.query():
-            if bool(host) and failed is None:
+            if bool(_PINNED[slot]) and failed is None:
                 failed = message
+            _FREE_SLOTS.append(slot)
         else:
-            keep.append((host, ev, message))
+            keep.append((slot, ev, message))
     _PENDING[:] = keep
     assert failed is None, failed
 
@@ -132,6 +137,47 @@ def uniform_upsample(poly, p_num, kind=POLY_RAW, check_status=True, deferred=Non
     elif check_status and n:
         _assert_status([status])
     return out, start
+
+
+def octagon_upsample(ext_points, p_num, clamp_max=None, override=None, override_mask=None, deferred=None,
+                     check_status=True):
+    """DsnakeHead.forward's extreme-point clamp (dsnake_head.py:800-805), ground-truth override
+    (:811-817) and get_octagon (:808-810 -> 373-411) in ONE launch.
+
+    ext_points (N,4,2) f32; clamp_max = (x_max, y_max) or None; override (N,4,2) with
+    override_mask (N,) bool: rows taken from `override` unclamped.  Returns (points (N,p_num,2),
+    ext_used (N,4,2): the points the octagons were built from, edge_start_idx (N,12) i64)."""
+    _need_gpu(ext_points, override, override_mask)
+    if ext_points.dim() != 3 or tuple(ext_points.shape[1:]) != (4, 2):
+        raise RuntimeError("octagon_upsample: extreme points must be (N,4,2)")
+    # a strided view (every 10th vertex of the init ring) is read in place: no copy kernel
+    if ext_points.dtype != torch.float32 or ext_points.stride(2) != 1 or ext_points.stride(1) < 2 or \
+            (ext_points.size(0) > 1 and ext_points.stride(0) < 2):
+        ext_points = _f32c(ext_points)
+    n = ext_points.size(0)
+    if (override is None) != (override_mask is None):
+        raise RuntimeError("octagon_upsample: override and override_mask go together")
+    if override is not None:
+        override = _f32c(override)
+        override_mask = override_mask.to(torch.uint8).contiguous()
+        if tuple(override.shape) != (n, 4, 2) or override_mask.numel() != n:
+            raise RuntimeError("octagon_upsample: override (N,4,2) / override_mask (N,) expected")
+    dev = ext_points.device
+    out = torch.empty((n, p_num, 2), dtype=torch.float32, device=dev)
+    used = torch.empty((n, 4, 2), dtype=torch.float32, device=dev)
+    start = torch.empty((n, 12), dtype=torch.int64, device=dev)
+    status = torch.empty((n,), dtype=torch.int32, device=dev)
+    cx, cy = (float(clamp_max[0]), float(clamp_max[1])) if clamp_max is not None else (0.0, 0.0)
+    with torch.cuda.device(dev):
+        check(lib().dance_octagon_upsample(ptr(ext_points), max(ext_points.stride(0), 2), ext_points.stride(1),
+                                           ptr(override), ptr(override_mask),
+                                           int(clamp_max is not None), cx, cy, n, int(p_num), ptr(out), ptr(used),
+                                           ptr(start), ptr(status), current_stream()), "octagon_upsample")
+    if deferred is not None:
+        deferred.append(status)
+    elif check_status and n:
+        _assert_status([status])
+    return out, used, start
 
 
 def check_upsample_status(deferred):

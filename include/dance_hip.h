@@ -82,7 +82,11 @@ int dance_nms_sorted_plain(const float *boxes_sorted, int n, float thresh, uint6
  * (DANCE_NMS_STATIC_MAX), larger lists return hipErrorInvalidValue with a text naming
  * dance_nms_sorted_plain.  Same results as dance_nms_sorted_plain, bit for bit.  All calls on
  * one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race;
- * serialise them or use the workspace form.  Nothing has to be cleared between calls. */
+ * serialise them or use the workspace form.  Nothing has to be cleared between calls.
+ * Under HIP graph capture: make ONE call per device outside the capture first (the address
+ * look-up of the first call may load the code object, which allocates and synchronises), and keep
+ * the current device equal to the device that owns `stream` (the array is picked by hipGetDevice;
+ * a stream of another device is refused with hipErrorInvalidDevice). */
 #define DANCE_NMS_STATIC_MAX 4096
 int dance_nms_sorted_plain_static(const float *boxes_sorted, int n, float thresh, int64_t *keep,
                                   int32_t *count, void *stream);
@@ -274,6 +278,21 @@ enum {
  * asserts, snake_head.py:782); such rows are zero-filled.  e <= 64, p_num <= 4096. */
 int dance_uniform_upsample(int kind, const float *src, int n, int e, int p_num, float *out,
                            int64_t *edge_start_idx, int32_t *status, void *stream);
+
+/* dance_uniform_upsample(DANCE_POLY_OCTAGON) with what DsnakeHead.forward does to the init snake's
+ * extreme points in front of get_octagon (dsnake_head.py:800-817) folded into the load: clamp != 0
+ * clamps x to [0, x_max] and y to [0, y_max] (tensor.clamp_: NaN stays NaN); where override_mask[i]
+ * (n, u8; NULL together with override_pts) is non-zero the instance's points are taken from
+ * override_pts (n,4,2) instead (ground-truth extreme points, never clamped).  ext_used (n,4,2) or
+ * NULL receives the points the octagon was built from (the module's `ext_points`).
+ * ext_points is read with strides (floats): instance i, point k at ext_points + i * poly_stride +
+ * k * point_stride -- (8, 2) for a dense (n,4,2) tensor, (80, 20) for every 10th vertex of the init
+ * snake's (n,40,2) ring (`pred[:, ::10]`, dsnake_head.py:745) without a copy. */
+int dance_octagon_upsample(const float *ext_points, int64_t poly_stride, int64_t point_stride,
+                           const float *override_pts,
+                           const uint8_t *override_mask, int clamp, float x_max, float y_max, int n,
+                           int p_num, float *out, float *ext_used, int64_t *edge_start_idx,
+                           int32_t *status, void *stream);
 
 /* ----------------------------------------------------------------- layout ---------- */
 /* (b, c_total, hw) NCHW -> feat (b, hw, c_total - att_channels) NHWC and, when

@@ -47,3 +47,19 @@ def test_struct_layout_matches_header():
 
     # 4 + 28 + 2 + 1 + 2 + 2 + 2 pointers, 7 ints dilation, 1 int feat_channels
     assert ctypes.sizeof(_lib.SnakeNetStruct) == 41 * 8 + 8 * 4
+
+
+def test_device_code_has_no_packed_fp32_forms():
+    """The library is built with -packed-fp32-ops after v_pk_{fma,mul,add}_f32 gave wrong values in
+    lanes 48..63 beside MFMA waves (dance_amd/build.py NOPK).  A toolchain that stops
+    honouring the switch would bring them back silently: look at the ISA of every gfx950 code object
+    of the library that ships."""
+    from dance_amd import _lib, build
+
+    if not os.path.exists(build.OBJDUMP):
+        pytest.skip("llvm-objdump not installed")
+    counts = build.device_isa_counts(_lib.SO_PATH)
+    assert counts["code_objects"] >= len(build.SOURCES)
+    assert counts["v_mfma_f32"] > 1000            # the disassembly really is the kernels'
+    for name in build.PACKED_FP32:
+        assert counts[name] == 0, "%d %s instructions in libdance_hip.so" % (counts[name], name)

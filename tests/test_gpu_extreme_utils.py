@@ -234,3 +234,46 @@ def test_batched_nms_many_equals_one_call_per_list(device):
     assert ml_nms.batched_nms_many([], [], [], 0.5) == []
     empty = ml_nms.batched_nms_many([boxes[1].to(device)] * 2, [scores[1].to(device)] * 2, [idxs[1].to(device)] * 2, 0.5)
     assert [e.numel() for e in empty] == [0, 0]
+
+
+def test_octagon_upsample_clamp_and_override_in_one_launch(device):
+    """ops.octagon_upsample = DsnakeHead.forward's clamp of the init snake's extreme points to the
+    image (dsnake_head.py:800-805), the ground-truth override (:811-817) and get_octagon (:808-810)
+    in one launch, reading `pred[:, ::10]` in place: bit-exact against torch.clamp / torch.where +
+    the plain octagon resampler, NaN and out-of-image points included."""
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 300, 400, 608
+    ring = torch.rand((n, 40, 2), generator=g) * torch.tensor([w + 80.0, h + 80.0]) - 40.0   # in and out of the image
+    # plausible extreme points: top, left, bottom, right of a box around a centre
+    c = torch.rand((n, 2), generator=g) * torch.tensor([w * 1.0, h * 1.0])
+    r = torch.rand((n, 2), generator=g) * 60 + 5
+    ring[:, 0] = c - torch.stack([torch.zeros(n), r[:, 1]], 1)
+    ring[:, 10] = c - torch.stack([r[:, 0], torch.zeros(n)], 1)
+    ring[:, 20] = c + torch.stack([torch.zeros(n), r[:, 1]], 1)
+    ring[:, 30] = c + torch.stack([r[:, 0], torch.zeros(n)], 1)
+    ring[7, 20, 0] = float("nan")
+    ring = ring.to(device)
+    view = ring[:, ::10]
+    gt = (torch.rand((n, 4, 2), generator=g) * 300 + 20).to(device)
+    mask = (torch.rand(n, generator=g) < 0.3).to(device)
+    lo = torch.zeros(2, device=device)
+    hi = torch.tensor([w - 1.0, h - 1.0], device=device)
+    for use_gt in (False, True):
+        want_ext = torch.clamp(view, min=lo, max=hi)
+        if use_gt:
+            want_ext = torch.where(mask[:, None, None], gt, want_ext)
+        want_pts, want_start = ops.uniform_upsample(want_ext.contiguous(), 128, kind=ops.POLY_OCTAGON, check_status=False)
+        pts, used, start = ops.octagon_upsample(view, 128, clamp_max=(w - 1.0, h - 1.0),
+                                                override=gt if use_gt else None,
+                                                override_mask=mask if use_gt else None, check_status=False)
+        assert torch.equal(torch.isnan(used), torch.isnan(want_ext))
+        assert torch.equal(torch.nan_to_num(used), torch.nan_to_num(want_ext))
+        assert torch.equal(start, want_start)
+        assert torch.equal(torch.isnan(pts), torch.isnan(want_pts))
+        assert torch.equal(torch.nan_to_num(pts), torch.nan_to_num(want_pts))
+    # no clamp, dense input: the plain resampler
+    dense = view.contiguous()
+    a, used, s = ops.octagon_upsample(dense, 128, check_status=False)
+    b, s2 = ops.uniform_upsample(dense, 128, kind=ops.POLY_OCTAGON, check_status=False)
+    assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) and torch.equal(s, s2)
+    assert torch.equal(torch.nan_to_num(used), torch.nan_to_num(dense))

@@ -201,3 +201,38 @@ def test_peeled_remainder_equals_one_stream(device, monkeypatch):
         assert d.peel_count(2 * cus - 1, torch.device(device)) == 0
         assert d.peel_count(6 * cus, torch.device(device)) == 0
         assert d.peel_count(d.MAX_CHUNK + 1, torch.device(device)) == 0
+
+
+def test_config1_single_image_100x128_every_contour(device):
+    """BASELINE config 1 at FULL size -- the reference's own CPU-runnable case and its published
+    inference mode (one image, Dance.single_test dance.py:52): (1, 257, 200, 304) features, 100 x 128,
+    image_idx None, so clip_locations' quirk is live (only contour 0 is clamped, snake_head.py:1718).
+    ALL 100 contours against the oracle: the free-running chain (band-limited features) and every
+    iteration on identical inputs, 1e-4 norm-wise and 0.02 px."""
+    n, v = 100, 128
+    cfg, sd, _ = dance_state_dict(1236, v)
+    nets = [snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer%d." % i), device) for i in range(3)]
+    feats = _features(1, 256, 1500, device)
+    boxes = synthetic.make_boxes(n, HF * 4, WF * 4, 82)
+    boxes[0] = torch.tensor([-30.0, -20.0, 90.0, 70.0])       # contour 0 starts outside: the clamp acts
+    boxes[1] = torch.tensor([WF * 4 - 60.0, HF * 4 - 50.0, WF * 4 + 25.0, HF * 4 + 30.0])   # contour 1: it must not
+    whs = torch.stack([boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], 1)
+    init_ref, _ = snake_ref.uniform_upsample(snake_ref.box_polygon(boxes)[None], v)
+    init, _ = ops.uniform_upsample(boxes.to(device), v, kind=ops.POLY_BOX)
+    assert torch.equal(init.cpu(), init_ref)
+    want = snake_ref.dance_deform(sd, feats.cpu(), init_ref, None, (HF * 4, WF * 4), whs)
+    d = snake.ContourDeformer(nets)
+    got = d.deform(feats, init, None, (HF * 4, WF * 4), whs.to(device))
+    f = d.prepare_features(feats)
+    prev = init
+    for it in range(3):
+        assert got[it].shape == (n, v, 2)
+        assert coord_rel_err(got[it], want[it]) < REL_TOL, ("chain", it)
+        one = d.evolve(it, *f, prev, None, whs.to(device), use_att=it > 0, clip_first=True,
+                       clip_max=(WF * 4 - 1, HF * 4 - 1))
+        assert_coords_close(one, want[it], "config 1, iteration %d, all contours" % it)
+        prev = want[it].to(device)
+    # the quirk at full size: contour 0 inside the image, contour 1 free to leave it
+    last = got[-1].cpu()
+    assert float(last[0, :, 0].min()) >= 0.0 and float(last[0, :, 1].min()) >= 0.0
+    assert float(want[-1][1, :, 0].max()) > WF * 4 - 1 and torch.equal(last[1] > WF * 4 - 1, want[-1][1] > WF * 4 - 1)
