@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 13
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -42,15 +42,27 @@ class SnakeNet16Struct(ctypes.Structure):
         ("res_w", c_void_p * 7), ("res_bs", c_void_p * 7), ("res_scale", c_void_p * 7),
         ("res_shift", c_void_p * 7),
         ("fuse_w", c_void_p), ("fuse_bs", c_void_p), ("pred0_wg", c_void_p), ("pred0_b", c_void_p),
-        ("fuse_w_split", c_void_p), ("pred0_w_split", c_void_p),
         ("pred1_w", c_void_p), ("pred1_bs", c_void_p),
         ("pred2_w", c_void_p), ("pred2_b", c_void_p),
-        ("head_winv", c_float), ("res_winv", c_float * 7), ("fuse_winv", c_float),
-        ("pred1_winv", c_float),
+        ("head_winv", c_float), ("res_winv", c_float * 7), ("res_rmul", c_float * 7), ("fuse_winv", c_float),
+        ("pred0_winv", c_float), ("pred1_winv", c_float),
         ("dilation", c_int * 7),
         ("feat_channels", c_int),
         ("head_wd", c_void_p),
+        ("head_wd_winv", c_float),
     ]
+
+
+class PolicyStruct(ctypes.Structure):
+    """Mirror of `dance_policy` (include/dance_hip.h); the defaults are the library's."""
+
+    _fields_ = [("few_contour_forms", c_int), ("fuse_tail_split", c_int), ("tail_group", c_int)]
+
+    def __init__(self, few_contour_forms=1, fuse_tail_split=1, tail_group=0):
+        super().__init__(int(few_contour_forms), int(fuse_tail_split), int(tail_group))
+
+
+ABSMAX_WORDS = 8            # DANCE_ABSMAX_WORDS
 
 
 class InitFuse16Struct(ctypes.Structure):
@@ -80,7 +92,7 @@ SIGNATURES = {
     "dance_nhwc_to_p16img": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "dance_upsample2x_add": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_conv3x3_16": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_nms_sorted": (c_int, [P, c_int, c_float, P, P, P, P]),
     "dance_nms_sorted_plain": (c_int, [P, c_int, c_float, P, P, P, P]),
     "dance_nms_sorted_plain_static": (c_int, [P, c_int, c_float, P, P, P]),
@@ -101,7 +113,8 @@ SIGNATURES = {
     "dance_multisegment_matching": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_uniform_upsample": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P]),
     "dance_octagon_upsample": (c_int, [P, c_int64, c_int64, P, P, c_int, c_float, c_float, c_int, c_int, P, P, P, P, P]),
-    "dance_nchw_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_nchw_to_nhwc": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_feature_absmax": (c_int, [P, c_int, c_int64, P, P]),
     "dance_gather_features": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, P]),
     "dance_circconv": (c_int, [P, c_int64, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int,
@@ -116,36 +129,28 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_float, c_float, c_int, POINTER(c_void_p), P]),
     "dance_conv16": (c_int, [P, c_int64, c_int64, P, P, c_float, P, P, P, c_int, c_int, c_int, P,
-                             c_int64, c_int64, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dance_fuse16": (c_int, [P, c_int64, c_int64, P, P, c_float, P, P, P, c_int64, c_int64, c_int,
-                             c_int, c_int, P]),
-    "dance_fuse16_parts": (c_int, [c_int, c_int]),
-    "dance_fuse16_raw": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int,
-                                 c_int, P]),
+                             c_int64, c_int64, P, c_int64, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_fuse16_parts": (c_int, [c_int, c_int, POINTER(PolicyStruct)]),
     "dance_fuse16w_supported": (c_int, [c_int, c_int]),
-    "dance_fuse16w_tail_split": (c_int, [c_int, c_int]),
-    "dance_fuse16w_raw_split": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int, c_int,
-                                        c_int, P]),
-    "dance_fuse16w_raw": (c_int, [P, c_int64, c_int64, P, P, c_float, P, c_int64, c_int64, P, c_int, c_int, c_int,
-                                  c_int, P]),
+    "dance_fuse16w_tail_split": (c_int, [c_int, c_int, POINTER(PolicyStruct)]),
+    "dance_fuse16w_raw_split": (c_int, [P, c_int64, c_int64, P, P, c_float, c_float, P, c_int64, c_int64, P, c_int,
+                                        c_int, c_int, c_int, P]),
+    "dance_fuse16w_raw": (c_int, [P, c_int64, c_int64, P, P, c_float, c_float, P, c_int64, c_int64, P, c_int, c_int,
+                                  c_int, c_int, P]),
     "dance_tail16": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_float, P, P, P, P, P, P, c_int,
-                             c_int, c_int, c_float, c_float, c_int, P]),
-    "dance_gather_head16": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
-                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dance_gather_head16w": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, c_int64, P, c_int, c_int,
-                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dance_xin_head16": (c_int, [P, c_int64, P, P, c_float, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
-    "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int, P]),
-    "dance_head_stack16": (c_int, [POINTER(SnakeNet16Struct), P, P, P, P, P, c_int64, c_int64, P, c_int, c_int,
-                                   c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dance_init_head16": (c_int, [P, P, P, P, c_float, P, P, P, P, P, c_float, P, P, P, c_int64, c_int, c_int,
-                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                             c_int, c_int, c_float, c_float, c_int, POINTER(PolicyStruct), P]),
+    "dance_gather_head16w": (c_int, [P, P, P, P, P, P, P, c_float, c_float, P, P, P, c_int64, P, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, POINTER(PolicyStruct), P]),
+    "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int,
+                                  POINTER(PolicyStruct), P]),
+    "dance_init_head16": (c_int, [P, P, P, P, c_float, P, P, P, P, P, c_float, c_float, P, P, P, c_int64, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "dance_snake_init16": (c_int, [POINTER(SnakeNet16Struct), POINTER(InitFuse16Struct), P, P, P, P, P,
-                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   POINTER(c_void_p), P]),
-    "dance_snake_evolve16": (c_int, [POINTER(SnakeNet16Struct), POINTER(SnakeNetStruct), P, P, P, P, P,
-                                     P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_int, c_int, c_float, c_float, c_int, POINTER(c_void_p), P]),
+                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P,
+                                   POINTER(PolicyStruct), POINTER(c_void_p), P]),
+    "dance_snake_evolve16": (c_int, [POINTER(SnakeNet16Struct), P, P, P, P, P, P, P, P, c_int64, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                     c_int, POINTER(PolicyStruct), POINTER(c_void_p), P]),
 }
 
 _lib = None

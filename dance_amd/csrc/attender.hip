@@ -295,9 +295,8 @@ extern "C" int dance_attender(const float *x, const float *w1, const float *gn1_
     double *stats1 = reinterpret_cast<double *>(workspace);
     double *stats2 = stats1 + (long long)b * AT_G * 2;
     float *y2 = reinterpret_cast<float *>(stats2 + (long long)b * AT_G * 2);
-    hipError_t e = hipMemsetAsync(stats1, 0, (size_t)2 * b * AT_G * 2 * 8, s);
-    if (e != hipSuccess)
-        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    if (int rc = dance::zero_async(stats1, (size_t)2 * b * AT_G * 2 * 8, s, __func__))
+        return rc;
     hipLaunchKernelGGL(k_att_stats1, dim3(dance::ceil_div(h * w, 256 * AT_PPT), b), dim3(256), 0, s, x, w1, stats1, h, w);
     const dim3 tiles2(dance::ceil_div(w, AT_TX), dance::ceil_div(h, AT_TY2), b);
     hipLaunchKernelGGL(k_att_conv2, tiles2, dim3(256), 0, s, x, w1, gn1_w, gn1_b, stats1, w2_packed, y2, stats2, eps,

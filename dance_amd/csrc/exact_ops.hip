@@ -18,7 +18,7 @@ char *error_buffer() { return g_error; }
 using dance::ceil_div;
 using dance::launch_check;
 
-extern "C" int dance_abi_version(void) { return 11; }
+extern "C" int dance_abi_version(void) { return 13; }
 extern "C" const char *dance_last_error(void) { return dance::error_buffer(); }
 
 extern "C" int dance_device_info(int *cu_count_host, int *lds_bytes_host)
@@ -469,8 +469,7 @@ static int nms_sorted_impl(const float *boxes_sorted, int n, float thresh, int p
     DANCE_REQUIRE(n >= 0 && n <= (1 << 20));      // 2^20 boxes would need a 137 GB mask: the Python
     DANCE_REQUIRE(count != nullptr);              // wrappers stop at 65,536 (dance_amd/ml_nms.py)
     if (n == 0)
-        return hipMemsetAsync(count, 0, sizeof(int32_t), (hipStream_t)stream) == hipSuccess
-                   ? 0 : dance::fail((int)hipErrorUnknown, __func__, "memset failed");
+        return dance::zero_async(count, sizeof(int32_t), (hipStream_t)stream, __func__);
     DANCE_REQUIRE(boxes_sorted && mask_ws && keep);
     const int cb = (n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)mask_ws;

@@ -315,6 +315,7 @@ struct GnArgs {
     float eps;
     _Float16 *out16;        // P16 image or null
     float *out_nhwc;        // (b, h, w, c) or null
+    uint32_t *absmax;       // with out_nhwc: (b, DANCE_ABSMAX_WORDS) max |output| per image, or null (p16.h)
     int c, group_ch;
     long long hw;
 };
@@ -322,11 +323,11 @@ struct GnArgs {
 __global__ __launch_bounds__(256) void k_gn_relu(GnArgs a)
 {
     // grid: (ceil(hw * 4 / 256), c / 16, b): thread -> (pixel, quarter of the 16-channel block)
+    __shared__ unsigned wm[16];
     const long long e = blockIdx.x * 256ll + threadIdx.x;
-    const long long p = e >> 2;
+    const long long p = min(e >> 2, a.hw - 1);                  // threads past the map redo its last pixel, store nothing
+    const bool live = (e >> 2) < a.hw;
     const int qtr = (int)(e & 3);
-    if (p >= a.hw)
-        return;
     const int blk = blockIdx.y, b = blockIdx.z, nblk = a.c >> 4;
     const int ch = blk * 16 + qtr * 4;
     const f32x4 v = *reinterpret_cast<const f32x4 *>(a.y + (((long long)b * nblk + blk) * a.hw + p) * 16 + qtr * 4);
@@ -346,6 +347,11 @@ __global__ __launch_bounds__(256) void k_gn_relu(GnArgs a)
         const float x = (v[i] - mu) * rstd * ga[i] + be[i];
         r[i] = x > 0.0f ? x : (x != x ? x : 0.0f);
     }
+    if (a.absmax != nullptr)                     // (uniform; holds a barrier)
+        dance::publish_absmax(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(0.0f, r[0]), r[1]), r[2]), r[3]),
+                              wm, a.absmax + b * DANCE_ABSMAX_WORDS, blockIdx.x + 5 * blockIdx.y);
+    if (!live)
+        return;
     if (a.out_nhwc) {
         *reinterpret_cast<f32x4 *>(a.out_nhwc + ((long long)b * a.hw + p) * a.c + ch) = f32x4{r[0], r[1], r[2], r[3]};
     } else {
@@ -431,9 +437,8 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
     a.stats = stats; a.h = h; a.w_ = w; a.cin = cin; a.cout = cout; a.group_ch = cout / groups;
     const long long tiles = (long long)b * ((h + C2_TR - 1) / C2_TR) * ((w + C2_TC - 1) / C2_TC);
     DANCE_REQUIRE(tiles * (cout / 128) < (1ll << 31));
-    hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)b * groups, (hipStream_t)stream);
-    if (e != hipSuccess)
-        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    if (int rc = dance::zero_async(stats, sizeof(double) * 2 * (size_t)b * groups, (hipStream_t)stream, __func__))
+        return rc;
     const size_t lds = 2 * C2_BYTES;
     if (int rc = dance::allow_lds((const void *)k_conv3x3_16, lds, __func__))
         return rc;
@@ -443,7 +448,7 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
 
 extern "C" int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamma,
                              const float *beta, float eps, int groups, void *out16, float *out_nhwc,
-                             int b, int c, int h, int w, void *stream)
+                             uint32_t *absmax, int b, int c, int h, int w, void *stream)
 {
     DANCE_REQUIRE(b >= 0 && c >= 16 && c % 16 == 0 && h >= 1 && w >= 1);
     DANCE_REQUIRE(groups >= 1 && c % groups == 0 && (c / groups) % 4 == 0);
@@ -455,6 +460,11 @@ extern "C" int dance_gn_relu(const float *y_blocked, const double *stats, const 
     a.y = y_blocked; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.out16 = (_Float16 *)out16; a.out_nhwc = out_nhwc; a.c = c; a.group_ch = c / groups;
     a.hw = (long long)h * w;
+    a.absmax = out_nhwc ? absmax : nullptr;
+    if (a.absmax != nullptr) {
+        if (int rc = dance::zero_async(absmax, sizeof(uint32_t) * DANCE_ABSMAX_WORDS * (size_t)b, (hipStream_t)stream, __func__))
+            return rc;
+    }
     hipLaunchKernelGGL(k_gn_relu, dim3((unsigned)((a.hw * 4 + 255) / 256), c / 16, b), dim3(256), 0,
                        (hipStream_t)stream, a);
     return launch_check(__func__);

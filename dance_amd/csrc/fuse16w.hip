@@ -1,13 +1,12 @@
-// fuse16w.hip -- the raw fusion kernel (k_fuse16r, snake16.hip: fusion 1024 -> 256 + max over the
-// ring part, prediction[0]'s 1024 state columns -> 256, one pass over the state; _SnakeNet.forward
-// snake_head.py:269-278) on v_mfma_f32_16x16x32_f16 with 16-wide vertex tiles.
+// fuse16w.hip -- the fusion kernel: fusion 1024 -> 256 + max over the ring part, and prediction[0]'s
+// 1024 state columns -> 256 (no row constant, no ReLU: tail16.hip), in one pass over the state
+// (_SnakeNet.forward snake_head.py:269-278), on v_mfma_f32_16x16x32_f16 with 16-wide vertex tiles.
 //
 // One 8-wave workgroup per contour part; wave w owns outputs 64 w .. 64 w + 63 (4 row tiles of 16)
 // x the part's CT column tiles of 16: 196 vertices run as 7 + 6 tiles (208 columns) instead of 4 + 3
 // tiles of 32 (224).  K = 1024 as 32 steps of 32 channels; 128-channel chunk images double-buffered
 // in LDS and staged by LDS-direct loads (no staging registers: the 4 x CT accumulator tiles and
 // the two rotating weight buffers of 4 row tiles x hi/lo fill the register file).
-// Same products per output element as k_fuse16r in another summation order.
 #include "common.h"
 #include "mfma16.h"
 #include "p16.h"
@@ -26,7 +25,8 @@ struct Fuse16wArgs {
     long long x_stride, x_slot_stride;
     const h8 *w;                  // [plane][1][128][512] words
     const float *bias_s;          // (512): fusion bias * 2^s, then zeros
-    float winv;
+    float winv;                   // fusion rows: 2^-s
+    float winv_p;                 // prediction rows: 2^-s' * 2^(scale of the stored block), p16.h
     _Float16 *y;                  // P16, 2 slots
     long long y_stride, y_slot_stride;
     int v;                        // ring length = vertices per row of x and y
@@ -141,6 +141,7 @@ __device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0
 #undef FW_LOAD_A
         int ce = c16, qe = q4;
         asm volatile("" : "+v"(ce), "+v"(qe));
+        const float winv = o0 < 256 ? a.winv : a.winv_p;
         if (o0 < 256) {
             // max over the part of the ring of the fusion output (snake_head.py:271-272): lane = vertex
             // column 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3; 16 butterflies side by side
@@ -153,7 +154,7 @@ __device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0
 #pragma unroll
                     for (int j = 0; j < CT; ++j)
                         if (j * 16 + ce < v)
-                            mm = dance::nan_max(acc[i][j][e] * a.winv, mm);
+                            mm = dance::nan_max(acc[i][j][e] * winv, mm);
                     m[i][e] = mm;
                 }
 #pragma unroll
@@ -187,7 +188,7 @@ __device__ __forceinline__ void fuse16w_body(const Fuse16wArgs &a, int n, int v0
                     float val[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        val[e] = acc[i][j][e] * a.winv;
+                        val[e] = acc[i][j][e] * winv;
                     dance::store_p16(yn + (ob >> 7) * a.y_slot_stride, vs, (ob & 127) >> 3, v0 + vv, (ob >> 2) & 1, val);
                 }
             }
@@ -234,15 +235,10 @@ int launch_fuse(const Fuse16wArgs &a, int n, int parts, int terms, hipStream_t s
     // (first chunk staged before any MFMA) and epilogue.  When the contour parts are whole rounds
     // of the CUs, one persistent workgroup per CU loops over its contours instead and stages the
     // next contour's first chunk behind the current one's last K steps: fusion 0.495 -> 0.483 ms at
-    // 1536 contours (same box, alternating).  DANCE_FUSE16_SLOTS=<k> forces k workgroups, 0 = one
-    // per contour part.
-    static const char *e = getenv("DANCE_FUSE16_SLOTS");
-    int slots = e && *e ? atoi(e) : -1;
-    if (slots < 0) {
-        const int cus = dance::cu_count();
-        const long long total = (long long)n * parts;
-        slots = cus > 0 && cus % parts == 0 && total >= 2ll * cus && total % cus == 0 ? cus / parts : 0;
-    }
+    // 1536 contours (same box, alternating).
+    const int cus = dance::cu_count();
+    const long long total = (long long)n * parts;
+    const int slots = cus > 0 && cus % parts == 0 && total >= 2ll * cus && total % cus == 0 ? cus / parts : 0;
     dim3 grid(slots > 0 && slots < n ? slots : n, parts);
     int rc;
     if (terms == 1) {
@@ -269,13 +265,22 @@ extern "C" int dance_fuse16w_supported(int parts, int v)
     return 0;
 }
 
-// trailing contours to run as half rings so that the last round of workgroups is a short one: n mod
-// CUs when that is at most half the CUs (and there is more than one round); 97..128 vertices only.
-// DANCE_FUSE16_TAIL_SPLIT=0: never (read per call).
-extern "C" int dance_fuse16w_tail_split(int n, int v)
+// parts a ring is split into (one workgroup each): 2 above 128 vertices, and for few contours (the
+// reference's one-image inference: ~100 instances on 256 CUs) rings of 97..128 vertices as two parts
+// of 64 as well, so that every contour keeps two CUs busy (policy.few_contour_forms, up to
+// DANCE_FEW_FUSE contours)
+extern "C" int dance_fuse16_parts(int n, int v, const dance_policy *policy)
 {
-    const char *e = getenv("DANCE_FUSE16_TAIL_SPLIT");
-    if ((e && atoi(e) == 0) || v <= 96 || v > 128)
+    const int small_n = dance::policy_or_default(policy).few_contour_forms ? DANCE_FEW_FUSE : 0;
+    return v > 128 || (v > 96 && n <= small_n) ? 2 : 1;
+}
+
+// trailing contours to run as half rings so that the last round of workgroups is a short one: n mod
+// CUs when that is at most half the CUs (and there is more than one round); 97..128 vertices only;
+// 0 when policy.fuse_tail_split is off.
+extern "C" int dance_fuse16w_tail_split(int n, int v, const dance_policy *policy)
+{
+    if (!dance::policy_or_default(policy).fuse_tail_split || v <= 96 || v > 128)
         return 0;
     const int cus = dance::cu_count();
     if (cus < 2)
@@ -285,7 +290,8 @@ extern "C" int dance_fuse16w_tail_split(int n, int v)
 }
 
 extern "C" int dance_fuse16w_raw_split(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
-                                       const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
+                                       const float *bias_scaled, float w_inv_scale, float pred_w_inv_scale,
+                                       void *y16, int64_t y_stride,
                                        int64_t y_slot_stride, float *gpart2, int n, int v, int n_split,
                                        int mfma_terms, void *stream)
 {
@@ -294,7 +300,7 @@ extern "C" int dance_fuse16w_raw_split(const void *x, int64_t x_stride, int64_t 
     DANCE_REQUIRE(x && w16 && bias_scaled && y16 && gpart2);
     Fuse16wArgs a;
     a.x = (const _Float16 *)x; a.x_stride = x_stride; a.x_slot_stride = x_slot_stride;
-    a.w = (const h8 *)w16; a.bias_s = bias_scaled; a.winv = w_inv_scale;
+    a.w = (const h8 *)w16; a.bias_s = bias_scaled; a.winv = w_inv_scale; a.winv_p = pred_w_inv_scale;
     a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
     a.gpart = gpart2; a.part_v = 64;
     const size_t lds = (size_t)2 * Geo<4, 16>::BYTES;
@@ -314,7 +320,8 @@ extern "C" int dance_fuse16w_raw_split(const void *x, int64_t x_stride, int64_t 
 }
 
 extern "C" int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
-                                 const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
+                                 const float *bias_scaled, float w_inv_scale, float pred_w_inv_scale,
+                                 void *y16, int64_t y_stride,
                                  int64_t y_slot_stride, float *gpart, int n, int v, int parts, int mfma_terms,
                                  void *stream)
 {
@@ -325,7 +332,7 @@ extern "C" int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot
     DANCE_REQUIRE(x && w16 && bias_scaled && y16 && gpart);
     Fuse16wArgs a;
     a.x = (const _Float16 *)x; a.x_stride = x_stride; a.x_slot_stride = x_slot_stride;
-    a.w = (const h8 *)w16; a.bias_s = bias_scaled; a.winv = w_inv_scale;
+    a.w = (const h8 *)w16; a.bias_s = bias_scaled; a.winv = w_inv_scale; a.winv_p = pred_w_inv_scale;
     a.y = (_Float16 *)y16; a.y_stride = y_stride; a.y_slot_stride = y_slot_stride; a.v = v;
     a.gpart = gpart;
     hipStream_t s = (hipStream_t)stream;

@@ -19,9 +19,11 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ src,
                                                       float *__restrict__ feat,
                                                       float *__restrict__ att, int c_total,
-                                                      int att_ch, int hw)
+                                                      int att_ch, int hw, uint32_t *absmax)
 {
     __shared__ float tile[TP][TP + 1];
+    __shared__ unsigned wm[16];
+    float amax = 0.0f;
     const int c = c_total - att_ch;
     const int px0 = blockIdx.x * TP;
     const int ch0 = blockIdx.y * TP;
@@ -58,8 +60,12 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ 
             tile[4 * q + 1][r + 16 * i] = v.y;
             tile[4 * q + 2][r + 16 * i] = v.z;
             tile[4 * q + 3][r + 16 * i] = v.w;
+            // (a NaN must win the max: its bit pattern does, fmaxf would drop it)
+            amax = dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(amax, v.x), v.y), v.z), v.w);
         }
     }
+    if (absmax != nullptr)                      // per-image max |feature| for the head block's input scale (p16.h);
+        dance::publish_absmax(amax, wm, absmax + ib * DANCE_ABSMAX_WORDS, blockIdx.x + 3 * blockIdx.y);   // holds a barrier
     __syncthreads();
     {   // write: rows = pixels, 16 lanes x float4 along channels
         const int q = t & 15, r = t >> 4;
@@ -88,7 +94,42 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ 
     }
 }
 
-extern "C" int dance_nchw_to_nhwc(const float *src, float *feat, float *att, int b, int c_total,
+// max |x| over each image of an NHWC feature tensor that did not come through dance_nchw_to_nhwc
+// or dance_gn_relu (which measure it on the way): one more read of the features
+__global__ __launch_bounds__(256) void k_feature_absmax(const float *__restrict__ feat, long long per_image,
+                                                        uint32_t *absmax)
+{
+    __shared__ unsigned wm[16];
+    const long long ib = blockIdx.y;
+    const float *f = feat + ib * per_image;
+    float amax = 0.0f;
+    const long long n4 = per_image >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(f) + i);
+        amax = dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(amax, v.x), v.y), v.z), v.w);
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < per_image; i += 256)
+            amax = dance::absmax_acc(amax, f[i]);
+    dance::publish_absmax(amax, wm, absmax + ib * DANCE_ABSMAX_WORDS, blockIdx.x);
+}
+
+extern "C" int dance_feature_absmax(const float *feat, int b, int64_t per_image, uint32_t *absmax, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && b <= 65535 && per_image >= 1);
+    if (b == 0)
+        return 0;
+    DANCE_REQUIRE(feat && absmax && ((uintptr_t)feat & 15) == 0 && (per_image % 4 == 0 || b == 1));
+    if (int rc = dance::zero_async(absmax, sizeof(uint32_t) * DANCE_ABSMAX_WORDS * (size_t)b, (hipStream_t)stream, __func__))
+        return rc;
+    const long long blocks = (per_image / 4 + 255) / 256;
+    const int gx = (int)(blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks));
+    hipLaunchKernelGGL(k_feature_absmax, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, feat, (long long)per_image,
+                       absmax);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_nchw_to_nhwc(const float *src, float *feat, float *att, uint32_t *absmax, int b, int c_total,
                                   int att_channels, int hw, void *stream)
 {
     DANCE_REQUIRE(b >= 0 && hw > 0 && (att_channels == 0 || att_channels == 1));
@@ -99,8 +140,12 @@ extern "C" int dance_nchw_to_nhwc(const float *src, float *feat, float *att, int
     DANCE_REQUIRE(b <= 65535);
     const int c = c_total - att_channels;
     dim3 grid(dance::ceil_div(hw, TP), dance::ceil_div(c, TP), b);
+    if (absmax != nullptr) {
+        if (int rc = dance::zero_async(absmax, sizeof(uint32_t) * DANCE_ABSMAX_WORDS * (size_t)b, (hipStream_t)stream, __func__))
+            return rc;
+    }
     hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, src, feat, att,
-                       c_total, att_channels, hw);
+                       c_total, att_channels, hw, absmax);
     return launch_check(__func__);
 }
 

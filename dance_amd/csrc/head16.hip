@@ -29,8 +29,9 @@ struct Head16Args {
     const h8 *w;                // head weights [plane][9][cin/8][128] words (feature blocks used)
     int cin;                    // padded input channels of w
     const h8 *wd;               // de_location im2col weights [plane][4][128] words
+    const uint32_t *absmax;     // (b, DANCE_ABSMAX_WORDS) max |feature| per image, or null (p16.h)
     const float *bias_s, *scale, *shift;
-    float winv;
+    float winv, wdinv;          // inverse weight scales of w / wd (powers of two)
     _Float16 *y;                // state slot 0 (P16)
     long long y_stride;
     int v;
@@ -66,12 +67,20 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
     float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
     if (a.deloc != DANCE_DELOC_NONE)
         dance::contour_bounds(loc_n, v, red, xmin, xmax, ymin, ymax);
+    // the block's input (features | de_location) is split at per-contour power-of-two scales (p16.h):
+    // folded into the tap weights and the de_location values, undone in the epilogue
+    const float dmax = a.deloc == DANCE_DELOC_DEMIN ? fmaxf(xmax - xmin, ymax - ymin) : 1.0f;
+    const dance::HeadInputScales hs = dance::head_input_scales(
+        a.winv, a.wdinv, a.absmax != nullptr,
+        a.absmax ? dance::feature_scale_exp(a.absmax + __builtin_amdgcn_readfirstlane(img) * DANCE_ABSMAX_WORDS) : 0,
+        a.deloc != DANCE_DELOC_NONE, dance::bound_scale_exp(dmax));
+    const float fs = hs.fs, ds = hs.ds;
     for (int vi = t; vi < v; vi += 256) {
         const float lx = loc_n[2 * vi], ly = loc_n[2 * vi + 1];
         dance::Taps tp = dance::bilinear_taps(lx, ly, a.hf, a.wf, a.reflection);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            tw[vi * 4 + k] = img_ok ? tp.w[k] : 0.0f;
+            tw[vi * 4 + k] = img_ok ? tp.w[k] * fs : 0.0f;
             toff[vi * 4 + k] = tp.off[k];
         }
         if (a.att_out != nullptr) {
@@ -86,8 +95,8 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
             a.att_out[nn * v + vi] = s;
         }
         if (a.deloc != DANCE_DELOC_NONE) {
-            dl[vi] = dance::deloc_value(lx, xmin, xmax, a.deloc);
-            dl[v + vi] = dance::deloc_value(ly, ymin, ymax, a.deloc);
+            dl[vi] = dance::deloc_value(lx, xmin, xmax, a.deloc) * ds;
+            dl[v + vi] = dance::deloc_value(ly, ymin, ymax, a.deloc) * ds;
         }
     }
 
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s + o0 + 16 * i + 4 * q4);
-        const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+        const f32x4 bv = {b4.x * fs, b4.y * fs, b4.z * fs, b4.w * fs};
 #pragma unroll
         for (int j = 0; j < CT; ++j)
             acc[i][j] = bv;
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 _Float16 p, q;
-                dance::split_half(val[i], p, q);
+                dance::split_half_sum(val[i], p, q);
                 hi[i] = p;
                 lo[i] = q;
             }
@@ -188,6 +197,7 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
 
     // epilogue: lane = vertex column 16 j + c16, row tile i = channels 16 i + 4 q4 .. + 3
     _Float16 *yslot = a.y + nn * a.y_stride;
+    const float winv = hs.inv;
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
         const int ob = o0 + 16 * i2 + 4 * q4;
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
             float val[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                val[i] = relu_nan(acc[i2][j][i] * a.winv) * sc[i] + sh[i];
+                val[i] = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
             dance::store_p16(yslot, v, ob >> 3, vv, (ob >> 2) & 1, val);
         }
     }
@@ -211,34 +221,19 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
 template <int RTG, int CT>
 int launch_head(const Head16Args &a, int n, int terms, size_t lds, hipStream_t s)
 {
+    // 65..128 vertices: 38.5 KB of LDS per workgroup, so three fit a CU when the kernel is held to
+    // 168 VGPRs (a few spilled outside the MFMA loop): a third workgroup's gather phases fill the
+    // other two's barrier waits (head 0.356 -> 0.335 ms at 1600 x 128, same box)
+    constexpr int MINB = RTG == 4 ? 3 : 2;
     int rc;
-    if constexpr (RTG == 4) {
-        // 65..128 vertices: 38.5 KB of LDS per workgroup, so three fit a CU when the kernel is held to
-        // 168 VGPRs (a few spilled outside the MFMA loop): a third workgroup's gather phases fill the
-        // other two's barrier waits.  Same box, alternating: head 0.356 -> 0.335 ms at 1600 x 128
-        // (cfg2 256.6k -> 258.9k contours/s).  DANCE_HEAD_WGS=2 restores two per CU.
-        static const char *e = getenv("DANCE_HEAD_WGS");
-        if (!(e && atoi(e) == 2)) {
-            if (terms == 1) {
-                if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 1, 3>, lds, "dance_gather_head16w")))
-                    return rc;
-                hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 1, 3>), dim3(n), dim3(256), lds, s, a);
-            } else {
-                if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 3, 3>, lds, "dance_gather_head16w")))
-                    return rc;
-                hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 3, 3>), dim3(n), dim3(256), lds, s, a);
-            }
-            return launch_check("dance_gather_head16w");
-        }
-    }
     if (terms == 1) {
-        if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 1>, lds, "dance_gather_head16w")))
+        if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 1, MINB>, lds, "dance_gather_head16w")))
             return rc;
-        hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 1>), dim3(n), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 1, MINB>), dim3(n), dim3(256), lds, s, a);
     } else {
-        if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 3>, lds, "dance_gather_head16w")))
+        if ((rc = dance::allow_lds((const void *)k_gather_head16w<RTG, CT, 3, MINB>, lds, "dance_gather_head16w")))
             return rc;
-        hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 3>), dim3(n), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_gather_head16w<RTG, CT, 3, MINB>), dim3(n), dim3(256), lds, s, a);
     }
     return launch_check("dance_gather_head16w");
 }
@@ -279,11 +274,19 @@ __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
     const long long plane = (long long)a.hf * a.wf;
 
     float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
-    if (a.deloc != DANCE_DELOC_NONE) {
+    if (a.deloc != DANCE_DELOC_NONE)
         dance::contour_bounds(loc_n, v, red, xmin, xmax, ymin, ymax);
+    // per-contour input scales, as in k_gather_head16w (both halves of a ring compute the same ones)
+    const float dmax = a.deloc == DANCE_DELOC_DEMIN ? fmaxf(xmax - xmin, ymax - ymin) : 1.0f;
+    const dance::HeadInputScales hs = dance::head_input_scales(
+        a.winv, a.wdinv, a.absmax != nullptr,
+        a.absmax ? dance::feature_scale_exp(a.absmax + __builtin_amdgcn_readfirstlane(img) * DANCE_ABSMAX_WORDS) : 0,
+        a.deloc != DANCE_DELOC_NONE, dance::bound_scale_exp(dmax));
+    const float fs = hs.fs, ds = hs.ds;
+    if (a.deloc != DANCE_DELOC_NONE) {
         for (int vi = t; vi < v; vi += 256) {
-            dl[vi] = dance::deloc_value(loc_n[2 * vi], xmin, xmax, a.deloc);
-            dl[v + vi] = dance::deloc_value(loc_n[2 * vi + 1], ymin, ymax, a.deloc);
+            dl[vi] = dance::deloc_value(loc_n[2 * vi], xmin, xmax, a.deloc) * ds;
+            dl[v + vi] = dance::deloc_value(loc_n[2 * vi + 1], ymin, ymax, a.deloc) * ds;
         }
     }
     // gather slot s = ring offset s - 4 from the half's first vertex
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
         dance::Taps tp = dance::bilinear_taps(lx, ly, a.hf, a.wf, a.reflection);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            tw[s * 4 + k] = img_ok ? tp.w[k] : 0.0f;
+            tw[s * 4 + k] = img_ok ? tp.w[k] * fs : 0.0f;
             toff[s * 4 + k] = tp.off[k];
         }
         if (a.att_out != nullptr && s >= 4 && s < len + 4) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s + o0 + 16 * i + 4 * q4);
-        const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+        const f32x4 bv = {b4.x * fs, b4.y * fs, b4.z * fs, b4.w * fs};
 #pragma unroll
         for (int j = 0; j < CT; ++j)
             acc[i][j] = bv;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 _Float16 p, q;
-                dance::split_half(val[i], p, q);
+                dance::split_half_sum(val[i], p, q);
                 hi[i] = p;
                 lo[i] = q;
             }
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
     }
 
     _Float16 *yslot = a.y + nn * a.y_stride;
+    const float winv = hs.inv;
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
         const int ob = o0 + 16 * i2 + 4 * q4;
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256, 3) void k_gather_head16h(Head16Args a, int h1)
             float val[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                val[i] = relu_nan(acc[i2][j][i] * a.winv) * sc[i] + sh[i];
+                val[i] = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
             dance::store_p16(yslot, v, ob >> 3, h0 + m, (ob >> 2) & 1, val);
         }
     }
@@ -450,10 +454,11 @@ int launch_head_halves(const Head16Args &a, int n, int terms, hipStream_t s)
 
 extern "C" int dance_gather_head16w(const float *feat, const float *att, const float *loc,
                                     const int32_t *image_idx, const void *w16, const void *wd16,
-                                    const float *bias_scaled, float w_inv_scale, const float *scale,
-                                    const float *shift, void *y16, int64_t y_stride, float *att_out, int n,
+                                    const float *bias_scaled, float w_inv_scale, float wd_inv_scale,
+                                    const float *scale, const float *shift, void *y16, int64_t y_stride, float *att_out, int n,
                                     int v, int b, int hf, int wf, int c, int padding_mode, int deloc_type,
-                                    int mfma_terms, void *stream)
+                                    int mfma_terms, const uint32_t *feat_absmax, const dance_policy *policy,
+                                    void *stream)
 {
     DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256);
@@ -465,57 +470,38 @@ extern "C" int dance_gather_head16w(const float *feat, const float *att, const f
         return 0;
     DANCE_REQUIRE(feat && loc && w16 && bias_scaled && scale && shift && y16);
     DANCE_REQUIRE(deloc_type == DANCE_DELOC_NONE || wd16 != nullptr);
+    DANCE_REQUIRE(dance::is_pow2_scale(w_inv_scale) && (deloc_type == DANCE_DELOC_NONE || dance::is_pow2_scale(wd_inv_scale)));
     Head16Args a;
     a.feat = feat; a.att = att; a.loc = loc; a.image_idx = image_idx; a.att_out = att_out; a.b = b;
     a.hf = hf; a.wf = wf; a.c = c; a.reflection = padding_mode == DANCE_PAD_REFLECTION; a.deloc = deloc_type;
     a.w = (const h8 *)w16; a.cin = (c + (deloc_type != DANCE_DELOC_NONE ? 2 : 0) + 31) & ~31;
-    a.wd = (const h8 *)wd16; a.bias_s = bias_scaled; a.scale = scale; a.shift = shift; a.winv = w_inv_scale;
+    a.wd = (const h8 *)wd16; a.absmax = feat_absmax; a.bias_s = bias_scaled; a.scale = scale; a.shift = shift; a.winv = w_inv_scale; a.wdinv = wd_inv_scale;
     a.y = (_Float16 *)y16; a.y_stride = y_stride; a.v = v;
     hipStream_t s = (hipStream_t)stream;
     // 14 and more column tiles do not fit the register file beside the rotating operand buffers:
-    // rings above 208 vertices run as two half rings (DANCE_HEAD_HALVES=0: k_gather_head16, 32-wide
-    // tiles, one workgroup per contour)
-    if (v > DANCE_HEAD16W_MAX_V) {
-        static const char *e = getenv("DANCE_HEAD_HALVES");
-        if (e && atoi(e) == 0)
-            return dance_gather_head16(feat, att, loc, image_idx, w16, wd16, bias_scaled, w_inv_scale, scale,
-                                       shift, y16, y_stride, att_out, n, v, b, hf, wf, c, padding_mode,
-                                       deloc_type, mfma_terms, stream);
+    // rings above 208 vertices run as two half rings
+    if (v > DANCE_HEAD16W_MAX_V)
         return launch_head_halves<5, 8>(a, n, mfma_terms, s);
-    }
     // fewer contours than CUs (one image's detections): 65..128-vertex rings as two half rings too,
-    // twice the workgroups at half the length each (DANCE_HEAD_SMALL_N: largest such n, 0 = never)
-    if (v > 64 && v <= 128) {
-        const char *e = getenv("DANCE_HEAD_SMALL_N");
-        if (n <= (e ? atoi(e) : 128))
-            return v <= 96 ? launch_head_halves<2, 3>(a, n, mfma_terms, s) : launch_head_halves<3, 4>(a, n, mfma_terms, s);
-    }
+    // twice the workgroups at half the length each (policy.few_contour_forms, up to DANCE_FEW_HEAD)
+    if (v > 64 && v <= 128 && dance::policy_or_default(policy).few_contour_forms && n <= DANCE_FEW_HEAD)
+        return v <= 96 ? launch_head_halves<2, 3>(a, n, mfma_terms, s) : launch_head_halves<3, 4>(a, n, mfma_terms, s);
     const int ct = (v + 15) / 16;
     // 129..208 vertices (9..13 tiles) as two half rings of 5, 6 or 7 tiles as well: twice the
-    // workgroups, three per CU (DANCE_HEAD_HALVES_MID=0: one workgroup per contour, two per CU)
+    // workgroups, three per CU
     if (v > 128) {
-        const char *e = getenv("DANCE_HEAD_HALVES_MID");
-        if (!(e && atoi(e) == 0)) {
-            if (ct <= 10)
-                return launch_head_halves<3, 5>(a, n, mfma_terms, s);
-            return ct <= 12 ? launch_head_halves<4, 6>(a, n, mfma_terms, s) : launch_head_halves<4, 7>(a, n, mfma_terms, s);
-        }
+        if (ct <= 10)
+            return launch_head_halves<3, 5>(a, n, mfma_terms, s);
+        return ct <= 12 ? launch_head_halves<4, 6>(a, n, mfma_terms, s) : launch_head_halves<4, 7>(a, n, mfma_terms, s);
     }
-    const int rtg = v <= 64 ? 2 : (v <= 128 ? 4 : 7);
+    const int rtg = v <= 64 ? 2 : 4;
     const size_t lds = (size_t)2 * 8 * (rtg * 32 + 1) * 16 + ((size_t)10 * v + 16) * sizeof(float);
     if (rtg == 2)
         return ct <= 2 ? launch_head<2, 2>(a, n, mfma_terms, lds, s)
                        : (ct == 3 ? launch_head<2, 3>(a, n, mfma_terms, lds, s) : launch_head<2, 4>(a, n, mfma_terms, lds, s));
-    if (rtg == 4) {
-        if (ct <= 5)
-            return launch_head<4, 5>(a, n, mfma_terms, lds, s);
-        if (ct == 6)
-            return launch_head<4, 6>(a, n, mfma_terms, lds, s);
-        return ct == 7 ? launch_head<4, 7>(a, n, mfma_terms, lds, s) : launch_head<4, 8>(a, n, mfma_terms, lds, s);
-    }
-    if (ct <= 10)
-        return launch_head<7, 10>(a, n, mfma_terms, lds, s);
-    if (ct <= 12)
-        return launch_head<7, 12>(a, n, mfma_terms, lds, s);
-    return launch_head<7, 13>(a, n, mfma_terms, lds, s);
+    if (ct <= 5)
+        return launch_head<4, 5>(a, n, mfma_terms, lds, s);
+    if (ct == 6)
+        return launch_head<4, 6>(a, n, mfma_terms, lds, s);
+    return ct == 7 ? launch_head<4, 7>(a, n, mfma_terms, lds, s) : launch_head<4, 8>(a, n, mfma_terms, lds, s);
 }

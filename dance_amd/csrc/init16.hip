@@ -25,6 +25,7 @@ namespace {
 struct InitHead16Args {
     const float *feat, *loc;      // (b, hf, wf, 256) NHWC, (n, v, 2)
     const int *image_idx;
+    const uint32_t *absmax;       // (b, DANCE_ABSMAX_WORDS) max |feature| per image, or null (p16.h)
     int b, hf, wf, reflection, deloc;
     const h8 *fw;                 // fuse, sampled half: [plane][1][32][256] words
     float fwinv;
@@ -32,7 +33,7 @@ struct InitHead16Args {
     const h8 *hw;                 // head block: [plane][9][36][128] words (258 -> 288 channels; feature blocks used)
     const h8 *hwd;                // head block, de_location channels as one K step: [plane][4][128] words (head16.hip)
     const float *hbs, *hscale, *hshift;
-    float hwinv;
+    float hwinv, hwdinv;          // inverse scales of hw / hwd (powers of two)
     _Float16 *y;                  // state slot 0 (P16)
     long long y_stride;
     int v;
@@ -72,6 +73,11 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
 
     float xmin, xmax, ymin, ymax;
     dance::contour_bounds(loc_n, v, red, xmin, xmax, ymin, ymax);
+    // the gathered features are split at the image's power-of-two scale (p16.h), folded into the ring
+    // vertices' tap weights (the centre's stay as they are: its feature feeds an fp32 GEMV)
+    const int f1 = a.absmax ? dance::feature_scale_exp(a.absmax + __builtin_amdgcn_readfirstlane(im) * DANCE_ABSMAX_WORDS)
+                            : 0;
+    const float fs1 = dance::pow2f(f1), fs1inv = dance::pow2f(-f1);
     for (int vi = t; vi <= v; vi += 256) {
 #pragma clang fp contract(off)
         float lx, ly;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
         dance::Taps tp = dance::bilinear_taps(lx, ly, a.hf, a.wf, a.reflection);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            tw[vi * 4 + k] = img_ok ? tp.w[k] : 0.0f;
+            tw[vi * 4 + k] = img_ok ? tp.w[k] * (vi < v ? fs1 : 1.0f) : 0.0f;
             toff[vi * 4 + k] = tp.off[k];
         }
     }
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     _Float16 p, q;
-                    dance::split_half(val[i], p, q);
+                    dance::split_half_sum(val[i], p, q);
                     hi[i] = p;
                     lo[i] = q;
                 }
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
 
     // ---- fuse GEMM: 256 outputs x v vertices, K = 256 (k = 1: no ring taps)
     auto nohook = [](int) __attribute__((always_inline)) {};
+    dance::HeadInputScales hs = {1.0f, 1.0f, 1.0f};   // scales of the head block's input (p16.h)
     {
         const int o0 = wave * 64;
         f32x16 acc[2][RT];
@@ -180,7 +187,10 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
                                                reinterpret_cast<const char *>(a.fw) + ((long long)(ch * 8) * C + o0) * 16,
                                                wlane, wts_b, wts_b, 2 * wbs_b, 1, 1, r, h, nohook);
         __syncthreads();                        // every wave is done reading the gathered images; rc is complete
-        // x = acc / 2^s + row constant, split again: the head block's input image
+        // x = acc / 2^s + row constant (true units, kept in the accumulators) and its largest magnitude
+        // over the contour: the head block's input is split at that scale (p16.h)
+        const float fw_eff = a.fwinv * fs1inv;
+        float xm = 0.0f;
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -190,6 +200,33 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
                 const float rcv[4] = {rc4.x, rc4.y, rc4.z, rc4.w};
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
+                    const bool in = rt * 32 + r < v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = acc[ot][rt][4 * gq + i] * fw_eff + rcv[i];
+                        acc[ot][rt][4 * gq + i] = x;
+                        xm = in ? fmaxf(xm, fabsf(x)) : xm;     // (a NaN does not bind: the result is NaN anyway)
+                    }
+                }
+            }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+            xm = fmaxf(__shfl_xor(xm, m, 64), xm);
+        if (lane == 0)
+            red[wave] = xm;
+        __syncthreads();
+        const float dmax = a.deloc == DANCE_DELOC_DEMIN ? fmaxf(xmax - xmin, ymax - ymin) : 1.0f;
+        const float xmax_all = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        hs = dance::head_input_scales(a.hwinv, a.hwdinv, true, dance::bound_scale_exp(xmax_all),
+                                      a.deloc != DANCE_DELOC_NONE, dance::bound_scale_exp(dmax));
+        const float fs2 = hs.fs;
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int row = (o0 >> 3) + ot * 4 + gq;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
                     const int vv = rt * 32 + r;
                     if (vv >= v)
                         continue;
@@ -197,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         _Float16 p, q;
-                        dance::split_half(acc[ot][rt][4 * gq + i] * a.fwinv + rcv[i], p, q);
+                        dance::split_half(acc[ot][rt][4 * gq + i] * fs2, p, q);
                         hi[i] = p;
                         lo[i] = q;
                     }
@@ -207,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
                 }
             }
     }
+    const float fs2 = hs.fs, ds2 = hs.ds;
     // de_location as one K step (head16.hip): word (block kb, vertex vi) = entries 8 kb .. 8 kb + 7 of
     // [dx(vi - 4 .. vi + 4), dy(vi - 4 .. vi + 4), 0 x 14]
     if (a.deloc != DANCE_DELOC_NONE)
@@ -219,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
                 if (k < 18) {
                     const int ch = k >= 9, tap = k - 9 * ch;
                     _Float16 p, q;
-                    dance::split_half(dl[ch * RT * 32 + ring16(vi, tap - 4, v)], p, q);
+                    dance::split_half(dl[ch * RT * 32 + ring16(vi, tap - 4, v)] * ds2, p, q);
                     hi[e] = p;
                     lo[e] = q;
                 }
@@ -237,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const float4 b4 = *reinterpret_cast<const float4 *>(a.hbs + o0 + 16 * i + 4 * q4);
-        const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+        const f32x4 bv = {b4.x * fs2, b4.y * fs2, b4.z * fs2, b4.w * fs2};
 #pragma unroll
         for (int j = 0; j < CT; ++j)
             acc[i][j] = bv;
@@ -275,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
                                                 reinterpret_cast<const char *>(a.hw) + ((long long)(ch * 8) * 128 + o0) * 16,
                                                 wlane, wps_b, wts_b, 4 * wbs_b, 9, 1, c16, q4, 0, nohook);
     _Float16 *yslot = a.y + nn * a.y_stride;
+    const float hwinv = hs.inv;
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
         const int ob = o0 + 16 * i2 + 4 * q4;
@@ -289,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_init_head16(InitHead16Args a)
             float val[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                val[i] = relu_nan(acc[i2][j][i] * a.hwinv) * sc[i] + sh[i];
+                val[i] = relu_nan(acc[i2][j][i] * hwinv) * sc[i] + sh[i];
             dance::store_p16(yslot, v, ob >> 3, vv, (ob >> 2) & 1, val);
         }
     }
@@ -301,9 +340,10 @@ extern "C" int dance_init_head16(const float *feat, const float *loc, const int3
                                  const void *fuse_w16, float fuse_w_inv_scale, const float *fuse_wg,
                                  const float *fuse_bias, const void *head_w16, const void *head_wd16,
                                  const float *head_bias_scaled,
-                                 float head_w_inv_scale, const float *head_scale, const float *head_shift,
+                                 float head_w_inv_scale, float head_wd_inv_scale, const float *head_scale, const float *head_shift,
                                  void *y16, int64_t y_stride, int n, int v, int b, int hf, int wf, int c,
-                                 int padding_mode, int deloc_type, int mfma_terms, void *stream)
+                                 int padding_mode, int deloc_type, int mfma_terms, const uint32_t *feat_absmax,
+                                 void *stream)
 {
     DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 64 && v % 4 == 0);
@@ -315,12 +355,13 @@ extern "C" int dance_init_head16(const float *feat, const float *loc, const int3
         return 0;
     DANCE_REQUIRE(feat && loc && fuse_w16 && fuse_wg && fuse_bias && head_w16 && head_wd16 && head_bias_scaled &&
                   head_scale && head_shift && y16);
+    DANCE_REQUIRE(dance::is_pow2_scale(head_w_inv_scale) && dance::is_pow2_scale(head_wd_inv_scale));
     InitHead16Args a;
-    a.feat = feat; a.loc = loc; a.image_idx = image_idx; a.b = b; a.hf = hf; a.wf = wf;
+    a.feat = feat; a.loc = loc; a.image_idx = image_idx; a.absmax = feat_absmax; a.b = b; a.hf = hf; a.wf = wf;
     a.reflection = padding_mode == DANCE_PAD_REFLECTION; a.deloc = deloc_type;
     a.fw = (const h8 *)fuse_w16; a.fwinv = fuse_w_inv_scale; a.fwg = fuse_wg; a.fb = fuse_bias;
     a.hw = (const h8 *)head_w16; a.hwd = (const h8 *)head_wd16; a.hbs = head_bias_scaled; a.hscale = head_scale; a.hshift = head_shift;
-    a.hwinv = head_w_inv_scale; a.y = (_Float16 *)y16; a.y_stride = y_stride; a.v = v;
+    a.hwinv = head_w_inv_scale; a.hwdinv = head_wd_inv_scale; a.y = (_Float16 *)y16; a.y_stride = y_stride; a.v = v;
     constexpr int RT = 2;
     const size_t lds = (size_t)4 * Geo<RT, 8>::BYTES + Geo<RT, 4>::BYTES + (256 + 2 * RT * 32 + 16) * sizeof(float);
     int rc = 0;

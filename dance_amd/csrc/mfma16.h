@@ -340,6 +340,10 @@ __device__ __forceinline__ void stage_commit(const u32x4 (&reg)[(StageGeo<RT, CB
 // (vmcnt retires in order, they only ever wait for more) -- so the CALLER must issue
 // s_waitcnt vmcnt(0) before the barrier that publishes the image (stage_dma_wait).
 //   lds_dst: byte offset of the image inside the workgroup's LDS (wave-uniform)
+// (M0 is on the asm's clobber list so that the compiler never carries a value of its own in it across
+// the statement; clang notes that M0 is a reserved register it will not save -- which is what is wanted)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 template <int RT, int CBC, int NW>
 __device__ __forceinline__ void stage_dma(int jlo, int jhi, const char *src, unsigned lds_dst, int v, int wave,
                                           int lane, int vs)
@@ -363,6 +367,8 @@ __device__ __forceinline__ void stage_dma(int jlo, int jhi, const char *src, uns
                 asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(g), "s"(l) : "memory", "m0");
         }
 }
+
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ void stage_dma_wait()
 {

@@ -405,9 +405,8 @@ extern "C" int dance_rle_decode(const uint32_t *counts, const int32_t *m, int n,
         return 0;
     DANCE_REQUIRE(counts && m && mask);
     const long long hw = (long long)h * w;
-    hipError_t e = hipMemsetAsync(mask, 0, (size_t)(hw * n), (hipStream_t)stream);
-    if (e != hipSuccess)
-        return dance::fail((int)e, __func__, hipGetErrorString(e));
+    if (int rc = dance::zero_async(mask, (size_t)(hw * n), (hipStream_t)stream, __func__))
+        return rc;
     hipLaunchKernelGGL(k_rle_decode, dim3(n), dim3(RT_THREADS), 0, (hipStream_t)stream, counts, m, cap, mask, hw);
     return launch_check(__func__);
 }

@@ -643,95 +643,43 @@ struct StageMarks {
 };
 
 // The fast mode after the head block (state slot 0 written): residual stack, fusion, tail.
-int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, bool head_stack, const float *loc,
+int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, const float *loc,
                         const float *whs, const float *att_s, float *out, int n, int v, int clip_first,
-                        float clip_x_max, float clip_y_max, int mfma_terms, StageMarks &mark, void *stream)
+                        float clip_x_max, float clip_y_max, int mfma_terms, const dance_policy *policy,
+                        StageMarks &mark, void *stream)
 {
     _Float16 *state = reinterpret_cast<_Float16 *>(w.state);     // (n, 8 slots) P16
     _Float16 *p1 = reinterpret_cast<_Float16 *>(w.p1);           // (n, 2 slots) P16
     const long long slot = 256ll * v, sstride = 8 * slot, pstride = 2 * slot;
-    static const int use_stack = getenv("DANCE_RES_STACK") ? atoi(getenv("DANCE_RES_STACK")) : 1;
-    // rings above 128 vertices: the 8-wave stack kernel (DANCE_RES_STACK_WIDE=0: one launch per block)
-    static const int use_stack_wide = getenv("DANCE_RES_STACK_WIDE") ? atoi(getenv("DANCE_RES_STACK_WIDE")) : 1;
-    if (head_stack) {
-        for (int i = 0; i < 7; ++i)
-            DANCE_TRY(mark());
-    } else if (use_stack && (v <= 128 || use_stack_wide)) {
-        // one launch for the 7 residual blocks; its time is booked on stage res0
-        DANCE_TRY(dance_res_stack16(net, state, sstride, slot, n, v, mfma_terms, stream));
-        for (int i = 0; i < 7; ++i)
-            DANCE_TRY(mark());
-    } else
-    for (int i = 0; i < 7; ++i) {
-        DANCE_TRY(dance_conv16(state + i * slot, sstride, slot, net->res_w[i], net->res_bs[i],
-                               net->res_winv[i], net->res_scale[i], net->res_shift[i], nullptr, 1, 1, 0,
-                               state + (i + 1) * slot, sstride, slot, nullptr, 0, n, v, 128, 128, 9,
-                               net->dilation[i], mfma_terms, stream));
+    // one launch for the 7 residual blocks; its time is booked on stage res0
+    DANCE_TRY(dance_res_stack16(net, state, sstride, slot, n, v, mfma_terms, policy, stream));
+    for (int i = 0; i < 7; ++i)
         DANCE_TRY(mark());
-    }
-    // default: the raw form of the fusion kernel (any ring length, rings above 128 vertices as
-    // two parts) + k_tail16 (parts' max, row constant, ReLU, prediction[2], prediction[4], offset
-    // update).  DANCE_TAIL16=0 restores the earlier sequence.
-    static const int use_tail = getenv("DANCE_TAIL16") ? atoi(getenv("DANCE_TAIL16")) : 1;
-    if (use_tail) {
-        const int parts = dance_fuse16_parts(n, v);
-        int tail_parts = parts;
-        float *gpart = w.gmax;                  // (n, parts <= 2, 256): gmax and h are adjacent pieces
-        DANCE_REQUIRE(w.h == w.gmax + (long long)n * 256);
-        // the fusion kernel on 16-wide vertex tiles (fuse16w.hip); DANCE_FUSE16_SHAPE=32: k_fuse16r
-        static const int fuse_shape = getenv("DANCE_FUSE16_SHAPE") ? atoi(getenv("DANCE_FUSE16_SHAPE")) : 16;
-        // one part per contour and a last round of workgroups that is mostly empty: its contours as
-        // half rings (fuse16w.hip, k_fuse16w_split); the tail kernel then reads two part slots
-        const int n_split = fuse_shape == 16 && parts == 1 ? dance_fuse16w_tail_split(n, v) : 0;
-        if (n_split > 0) {
-            DANCE_TRY(dance_fuse16w_raw_split(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
-                                              pstride, slot, gpart, n, v, n_split, mfma_terms, stream));
-            tail_parts = 2;
-        } else if (fuse_shape == 16 && dance_fuse16w_supported(parts, v))
-            DANCE_TRY(dance_fuse16w_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
-                                        pstride, slot, gpart, n, v, parts, mfma_terms, stream));
-        else
-            DANCE_TRY(dance_fuse16_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv, p1,
-                                       pstride, slot, gpart, n, v, mfma_terms, stream));
-        DANCE_TRY(mark());
-        DANCE_TRY(mark());      // row constant: inside the tail kernel
-        DANCE_TRY(mark());      // prediction[0]'s ReLU: inside the tail kernel
-        DANCE_TRY(mark());      // prediction[2]: the tail kernel, booked on the last stage
-        DANCE_TRY(dance_tail16(p1, pstride, slot, gpart, tail_parts, net->pred0_wg, net->pred0_b, net->pred1_w,
-                               net->pred1_bs, net->pred1_winv, net->pred2_w, net->pred2_b, loc,
-                               whs, att_s, out, n, v,
-                               clip_first, clip_x_max, clip_y_max, mfma_terms, stream));
-        DANCE_TRY(mark());
-        return 0;
-    }
-    if (v <= 128) {
-        DANCE_TRY(dance_fuse16(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv,
-                               net->pred0_wg, net->pred0_b, p1, pstride, slot, n, v, mfma_terms, stream));
-        DANCE_TRY(mark());
-        DANCE_TRY(mark());      // row constant: inside the fused kernel
-        DANCE_TRY(mark());      // prediction[0]: inside the fused kernel
+    // the fusion kernel (any ring length, rings above 128 vertices as two parts) + k_tail16 (parts' max,
+    // row constant, ReLU, prediction[2], prediction[4], offset update)
+    const int parts = dance_fuse16_parts(n, v, policy);
+    int tail_parts = parts;
+    float *gpart = w.gmax;                  // (n, parts <= 2, 256): gmax and h are adjacent pieces
+    DANCE_REQUIRE(w.h == w.gmax + (long long)n * 256);
+    // one part per contour and a last round of workgroups that is mostly empty: its contours as
+    // half rings (fuse16w.hip, k_fuse16w_split); the tail kernel then reads two part slots
+    const int n_split = parts == 1 ? dance_fuse16w_tail_split(n, v, policy) : 0;
+    if (n_split > 0) {
+        DANCE_TRY(dance_fuse16w_raw_split(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv,
+                                          net->pred0_winv, p1, pstride, slot, gpart, n, v, n_split, mfma_terms,
+                                          stream));
+        tail_parts = 2;
     } else {
-        // larger rings: the 512-output tile does not fit the register file; same weights
-        // (outputs 0..255 = fusion, 256..511 = prediction[0]) through three launches
-        DANCE_REQUIRE(net->fuse_w_split != nullptr && net->pred0_w_split != nullptr);
-        DANCE_TRY(dance_conv16(state, sstride, slot, net->fuse_w_split, net->fuse_bs, net->fuse_winv,
-                               nullptr, nullptr, nullptr, 0, 0, 1, nullptr, 0, 0, w.gmax, 0, n, v,
-                               1024, 256, 1, 1, mfma_terms, stream));
-        DANCE_TRY(mark());
-        DANCE_TRY(dance_row_constant(w.gmax, net->pred0_wg, net->pred0_b, w.h, n, 256, 256, stream));
-        DANCE_TRY(mark());
-        DANCE_TRY(dance_conv16(state, sstride, slot, net->pred0_w_split, nullptr, net->fuse_winv,
-                               nullptr, nullptr, w.h, 0, 1, 0, p1, pstride, slot, nullptr, 0, n, v,
-                               1024, 256, 1, 1, mfma_terms, stream));
-        DANCE_TRY(mark());
+        DANCE_TRY(dance_fuse16w_raw(state, sstride, slot, net->fuse_w, net->fuse_bs, net->fuse_winv,
+                                    net->pred0_winv, p1, pstride, slot, gpart, n, v, parts, mfma_terms, stream));
     }
-    DANCE_TRY(dance_conv16(p1, pstride, slot, net->pred1_w, net->pred1_bs, net->pred1_winv, nullptr,
-                           nullptr, nullptr, 0, 1, 0, nullptr, 0, 0, w.p2, 64ll * v, n, v, 256, 64, 1,
-                           1, mfma_terms, stream));
     DANCE_TRY(mark());
-    DANCE_TRY(dance_offset_update(w.p2, 64ll * v, net->pred2_w, net->pred2_b, loc,
-                                  whs, att_s, out,
-                                  n, v, 64, clip_first, clip_x_max, clip_y_max, stream));
+    DANCE_TRY(mark());      // row constant: inside the tail kernel
+    DANCE_TRY(mark());      // prediction[0]'s ReLU: inside the tail kernel
+    DANCE_TRY(mark());      // prediction[2]: the tail kernel, booked on the last stage
+    DANCE_TRY(dance_tail16(p1, pstride, slot, gpart, tail_parts, net->pred0_wg, net->pred0_b, net->pred1_w,
+                           net->pred1_bs, net->pred1_winv, net->pred2_w, net->pred2_b, loc, whs, att_s, out, n, v,
+                           clip_first, clip_x_max, clip_y_max, mfma_terms, policy, stream));
     DANCE_TRY(mark());
     return 0;
 }
@@ -742,66 +690,38 @@ int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, bool h
 // One evolve step in the fast precision mode (P16 activations, 3 x f16 MFMA): same stages,
 // fusion + row constant + prediction[0] fused into one kernel that reads the state once.
 // ------------------------------------------------------------------------------------
-extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const dance_snake_net *net32,
-                                    const float *feat, const float *att, const float *loc,
-                                    const int32_t *image_idx, const float *whs, const float *x_in,
-                                    float *out, void *workspace, int64_t workspace_bytes, int n, int v,
-                                    int b, int hf, int wf, int padding_mode, int deloc_type,
-                                    int individual_scale, int use_att, int clip_first,
-                                    float clip_x_max, float clip_y_max, int mfma_terms,
+extern "C" int dance_snake_evolve16(const dance_snake_net16 *net, const float *feat, const float *att,
+                                    const uint32_t *feat_absmax, const float *loc, const int32_t *image_idx,
+                                    const float *whs, float *out, void *workspace, int64_t workspace_bytes,
+                                    int n, int v, int b, int hf, int wf, int padding_mode, int deloc_type,
+                                    int individual_scale, int use_att, int clip_first, float clip_x_max,
+                                    float clip_y_max, int mfma_terms, const dance_policy *policy,
                                     void **stage_events_host, void *stream)
 {
     DANCE_REQUIRE(net != nullptr && n >= 0);
     DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     if (n == 0)
         return 0;
-    DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr);
+    DANCE_REQUIRE(workspace != nullptr && out != nullptr && loc != nullptr && feat != nullptr);
     DANCE_REQUIRE(v >= 16 && v <= 256 && v % 4 == 0);
     const int c = net->feat_channels;
     DANCE_REQUIRE(c >= 64 && c % 64 == 0 && c + 2 <= 272);
     DANCE_REQUIRE(!individual_scale || whs != nullptr);
     DANCE_REQUIRE(!use_att || att != nullptr);
-    DANCE_REQUIRE(x_in != nullptr || feat != nullptr);
-    (void)net32;
+    DANCE_REQUIRE(net->head_wd != nullptr || deloc_type == DANCE_DELOC_NONE);
     Workspace w = carve(workspace, n, v, 272);
     DANCE_REQUIRE(workspace_bytes >= w.bytes);
     _Float16 *state = reinterpret_cast<_Float16 *>(w.state);     // (n, 8 slots) P16
     const long long slot = 256ll * v, sstride = 8 * slot;
     StageMarks mark{stage_events_host, stream, "dance_snake_evolve16"};
     DANCE_TRY(mark());
-    if (x_in != nullptr) {
-        // precomputed fp32 input (Dsnake init): the head block of the fast mode, input split
-        // into hi/lo halves while it is staged
-        DANCE_TRY(dance_xin_head16(x_in, (long long)(c + 2) * v, net->head_w, net->head_bs, net->head_winv,
-                                   net->head_scale, net->head_shift, state, sstride, n, v, c, mfma_terms,
-                                   stream));
-    }
-    static const int use_stack = getenv("DANCE_RES_STACK") ? atoi(getenv("DANCE_RES_STACK")) : 1;
-    // opt-in (DANCE_HEAD_STACK=1): measured no faster than the two launches (experiments)
-    static const int use_head_stack = getenv("DANCE_HEAD_STACK") ? atoi(getenv("DANCE_HEAD_STACK")) : 0;
-    const bool head_stack = x_in == nullptr && use_stack && use_head_stack && v <= 128;
-    // head block on 16-wide vertex tiles (head16.hip); DANCE_HEAD_SHAPE=32: k_gather_head16
-    static const int head_shape16 = (getenv("DANCE_HEAD_SHAPE") ? atoi(getenv("DANCE_HEAD_SHAPE")) : 16) == 16;
-    if (head_stack) {
-        // gather + head block + the 7 residual blocks in one launch; its time is booked on stage head
-        DANCE_TRY(dance_head_stack16(net, feat, att, loc, image_idx, state, sstride, slot,
-                                     use_att ? w.att_s : nullptr, n, v, b, hf, wf, padding_mode, deloc_type,
-                                     mfma_terms, stream));
-    } else if (x_in == nullptr && net->head_wd != nullptr && head_shape16) {
-        DANCE_TRY(dance_gather_head16w(feat, att, loc, image_idx, net->head_w, net->head_wd, net->head_bs,
-                                       net->head_winv, net->head_scale, net->head_shift, state, sstride,
-                                       use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
-                                       deloc_type, mfma_terms, stream));
-    } else if (x_in == nullptr) {
-        DANCE_TRY(dance_gather_head16(feat, att, loc, image_idx, net->head_w, nullptr, net->head_bs,
-                                      net->head_winv, net->head_scale, net->head_shift, state, sstride,
-                                      use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode,
-                                      deloc_type, mfma_terms, stream));
-    }
+    DANCE_TRY(dance_gather_head16w(feat, att, loc, image_idx, net->head_w, net->head_wd, net->head_bs,
+                                   net->head_winv, net->head_wd_winv, net->head_scale, net->head_shift, state, sstride,
+                                   use_att ? w.att_s : nullptr, n, v, b, hf, wf, c, padding_mode, deloc_type,
+                                   mfma_terms, feat_absmax, policy, stream));
     DANCE_TRY(mark());
-    return evolve16_after_head(net, w, head_stack, loc, individual_scale ? whs : nullptr,
-                               use_att ? w.att_s : nullptr, out, n, v, clip_first, clip_x_max, clip_y_max,
-                               mfma_terms, mark, stream);
+    return evolve16_after_head(net, w, loc, individual_scale ? whs : nullptr, use_att ? w.att_s : nullptr, out,
+                               n, v, clip_first, clip_x_max, clip_y_max, mfma_terms, policy, mark, stream);
 }
 
 // ------------------------------------------------------------------------------------
@@ -814,6 +734,7 @@ extern "C" int dance_snake_init16(const dance_snake_net16 *net, const dance_init
                                   const float *feat, const float *loc, const int32_t *image_idx, float *out,
                                   void *workspace, int64_t workspace_bytes, int n, int v, int b, int hf,
                                   int wf, int padding_mode, int deloc_type, int mfma_terms,
+                                  const uint32_t *feat_absmax, const dance_policy *policy,
                                   void **stage_events_host, void *stream)
 {
     DANCE_REQUIRE(net != nullptr && fuse != nullptr && n >= 0);
@@ -828,10 +749,10 @@ extern "C" int dance_snake_init16(const dance_snake_net16 *net, const dance_init
     StageMarks mark{stage_events_host, stream, "dance_snake_init16"};
     DANCE_TRY(mark());
     DANCE_TRY(dance_init_head16(feat, loc, image_idx, fuse->w16, fuse->w_inv_scale, fuse->wg_center, fuse->bias,
-                                net->head_w, net->head_wd, net->head_bs, net->head_winv, net->head_scale,
+                                net->head_w, net->head_wd, net->head_bs, net->head_winv, net->head_wd_winv, net->head_scale,
                                 net->head_shift, w.state, 2048ll * v, n, v, b, hf, wf, 256, padding_mode, deloc_type, mfma_terms,
-                                stream));
+                                feat_absmax, stream));
     DANCE_TRY(mark());
-    return evolve16_after_head(net, w, false, loc, nullptr, nullptr, out, n, v, 0, 0.0f, 0.0f, mfma_terms,
+    return evolve16_after_head(net, w, loc, nullptr, nullptr, out, n, v, 0, 0.0f, 0.0f, mfma_terms, policy,
                                mark, stream);
 }

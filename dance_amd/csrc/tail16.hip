@@ -1,11 +1,12 @@
 // tail16.hip -- the end of a _SnakeNet in the fast precision mode, one launch:
 //   global state = max over the ring of the fusion output (reduced here over the parts
-//   k_fuse16r wrote)  ->  row constant of prediction[0] (its 256 global-state columns, a
+//   k_fuse16w wrote)  ->  row constant of prediction[0] (its 256 global-state columns, a
 //   256 x 256 GEMV per contour, snake_head.py:272-282)  ->  relu(prediction[0])  ->
 //   prediction[2] 256 -> 64 + ReLU (split-half f16 MFMA)  ->  prediction[4] 64 -> 2 (fp32)  ->
 //   tanh * wh, attention, loc + off, clip_locations (snake_head.py:1702-1727).
-// Replaces the end of k_fuse16 (row constant, ReLU), the prediction[2] launch of k_conv16s and
-// k_offset_update; the (n, 64, v) fp32 block between the last two never goes to HBM.
+// The (n, 64, v) fp32 block between prediction[2] and prediction[4] never goes to HBM.  p1 arrives at
+// the net's prediction scale 2^a_p (p16.h "Activation scales"); wg, pb, b1s and winv1 are packed
+// with that scale, so nothing here knows about it.
 //
 // One workgroup (4 waves) takes GC consecutive contours: the GEMV runs for all of them at once
 // (each 16-byte weight load feeds GC contours -- the 256 KB matrix would otherwise be re-read
@@ -270,7 +271,8 @@ extern "C" int dance_tail16(const void *p1, int64_t p1_stride, int64_t p1_slot_s
                             int parts, const float *wg, const float *pred0_bias, const void *w1_16,
                             const float *b1_scaled, float w1_inv_scale, const float *w3, const float *b3,
                             const float *loc, const float *whs, const float *att, float *out, int n, int v,
-                            int clip_first, float clip_x_max, float clip_y_max, int mfma_terms, void *stream)
+                            int clip_first, float clip_x_max, float clip_y_max, int mfma_terms,
+                            const dance_policy *policy, void *stream)
 {
     DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
     DANCE_REQUIRE(n >= 0 && v >= 16 && v <= 256 && parts >= 1 && parts <= 8);
@@ -287,9 +289,9 @@ extern "C" int dance_tail16(const void *p1, int64_t p1_stride, int64_t p1_slot_s
     // 3072; longer rings: behind, 0.127 vs 0.121 ms at 1536 x 196, 0.142 vs 0.138 ms at 256), else one.
     // Four was ahead when this kernel was written and is behind since the library is built without
     // packed fp32 forms (0.0816 vs 0.0745 ms at 1600 x 128), three is behind too.
-    // DANCE_TAIL16_GROUP=1|2|4 fixes it (read per call: the tests run all three).
-    const char *e = getenv("DANCE_TAIL16_GROUP");
-    const int group = e && *e ? atoi(e) : (n >= 1024 && v <= 128 ? 2 : 1);
+    // policy.tail_group = 1 | 2 | 4 fixes it (0 = this choice).
+    const int pg = dance::policy_or_default(policy).tail_group;
+    const int group = pg > 0 ? pg : (n >= 1024 && v <= 128 ? 2 : 1);
     if (group >= 4)
         return launch_tail_rt<4>(a, n, mfma_terms, (hipStream_t)stream);
     if (group >= 2)

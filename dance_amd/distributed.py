@@ -59,8 +59,10 @@ class ImageShard:
 def gather_shards(local, group=None):
     """The exchange step of a sharded sweep: every rank's deformed contours (n_r, V, 2), n_r
     differing with the instances per image, into the full (N, V, 2) set on every rank in the
-    original order: one tiny all-gather of the counts, then one padded all_gather_into_tensor."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    original order: one tiny all-gather of the counts, then one padded all_gather_into_tensor.
+    Without a process group there is nothing to exchange; WITH one the collectives run whatever the
+    world size -- a world of one rank (bench.py --force-dist) takes the same RCCL calls as eight."""
+    if not dist.is_available() or not dist.is_initialized():
         return local
     counts = gather_counts(local.size(0), local.device, group)
     return all_gather_contours(local, counts, group)
@@ -72,14 +74,16 @@ def all_gather_contours(local, counts=None, group=None):
 
     counts: list of n_r for all ranks when they differ (shards are padded to max(counts) so
     one all_gather_into_tensor moves everything); None when every rank holds the same n.
+    No early return at world size 1 (see gather_shards).
     """
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     n, v, two = local.shape
     if counts is None:
         out = torch.empty((world * n, v, two), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        CALLS["all_gather_into_tensor"] += 1
         return out
     if len(counts) != world or counts[dist.get_rank(group)] != n:
         raise ValueError("counts must list every rank's contour count")
@@ -90,7 +94,11 @@ def all_gather_contours(local, counts=None, group=None):
         padded[:n] = local
     out = torch.empty((world * m, v, two), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    CALLS["all_gather_into_tensor"] += 1
     return torch.cat([out[r * m:r * m + counts[r]] for r in range(world)], dim=0)
+
+
+CALLS = {"all_gather_into_tensor": 0}       # collectives issued by this process (bench.py reports it)
 
 
 def gather_counts(n_local, device, group=None):
@@ -99,4 +107,5 @@ def gather_counts(n_local, device, group=None):
     t = torch.tensor([n_local], dtype=torch.int64, device=device)
     out = torch.empty((world,), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(out, t, group=group)
+    CALLS["all_gather_into_tensor"] += 1
     return [int(x) for x in out.tolist()]

@@ -437,12 +437,12 @@ class DsnakeHead(_SnakeHeadBase):
 
     def init_contours(self, d, feat, init_locations, idx, one_launch=None):
         """The init snake's deformed ring (dsnake_head.py:718-744).  one_launch (default: whenever
-        the deformer supports it, DANCE_INIT16=0 to switch off): gather + centre feature + fuse +
+        the deformer supports it; `self.one_launch_init = False` switches it off): gather + centre feature + fuse +
         de_location + head block as one kernel of the fast precision mode (csrc/init16.hip);
         otherwise separate launches with `fuse` as an exact fp32 convolution."""
         c = feat.shape[-1]
         if one_launch is None:
-            one_launch = os.environ.get("DANCE_INIT16", "1") != "0"
+            one_launch = getattr(self, "one_launch_init", True)
         if one_launch and d.supports_init_evolve(c, init_locations.shape[1]):
             return d.init_evolve(0, feat, init_locations, idx, self._fuse16)
         sampled, _ = ops.gather_features(feat, None, init_locations, idx, ops.PAD_ZEROS, "demin")
@@ -464,6 +464,7 @@ class DsnakeHead(_SnakeHeadBase):
         side = ContourDeformer(d.nets, padding="zeros", de_loc_type="demin", individual_scale=False,
                                attention=False, precision=d.precision)
         side.nets = d.nets
+        side.policy = d.policy
         return side
 
     def _chain(self, d, nhwc, init_locations, idx, gt_exts, gt_mask, deferred):

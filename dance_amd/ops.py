@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from ._lib import check, current_stream, lib, ptr
+from ._lib import ABSMAX_WORDS, check, current_stream, lib, ptr
 
 POLY_RAW, POLY_BOX, POLY_QUAD, POLY_OCTAGON = 0, 1, 2, 3
 PAD_ZEROS, PAD_REFLECTION = 0, 1
@@ -198,17 +198,47 @@ def contour_upsample_2x(locations):
     return out
 
 
+ABSMAX_ATTR = "_dance_absmax"
+
+
+def absmax_of(feat_nhwc):
+    """The per-image max |feature| words (B, ABSMAX_WORDS) int32 the fast mode's head block scales its
+    input by (include/dance_hip.h "Range").  Tensors this package produces (nchw_to_nhwc,
+    bottom_out16) carry them, measured on the way out; any other NHWC tensor is measured here --
+    one more read of it, on every call (never cached: the caller may change it in place)."""
+    words = getattr(feat_nhwc, ABSMAX_ATTR, None)
+    if words is not None:
+        return words
+    return feature_absmax(feat_nhwc)
+
+
+def feature_absmax(feat_nhwc):
+    """dance_feature_absmax: (B, ...) fp32 dense -> (B, ABSMAX_WORDS) int32 float bit patterns."""
+    _need_gpu(feat_nhwc)
+    feat_nhwc = _f32c(feat_nhwc)
+    b = feat_nhwc.size(0)
+    words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=feat_nhwc.device)
+    if b:
+        with torch.cuda.device(feat_nhwc.device):
+            check(lib().dance_feature_absmax(ptr(feat_nhwc), b, feat_nhwc[0].numel(), ptr(words), current_stream()),
+                  "feature_absmax")
+    return words
+
+
 def nchw_to_nhwc(features, att_channels):
-    """(B, att+C, Hf, Wf) NCHW -> ((B,Hf,Wf,C) NHWC, (B,Hf,Wf) attention plane or None)."""
+    """(B, att+C, Hf, Wf) NCHW -> ((B,Hf,Wf,C) NHWC, (B,Hf,Wf) attention plane or None).  The NHWC
+    tensor carries its per-image max |feature| words (`absmax_of`), measured in the same pass."""
     _need_gpu(features)
     features = _f32c(features)
     b, ct, hf, wf = features.shape
     c = ct - att_channels
     feat = torch.empty((b, hf, wf, c), dtype=torch.float32, device=features.device)
     att = torch.empty((b, hf, wf), dtype=torch.float32, device=features.device) if att_channels else None
+    words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=features.device)
     with torch.cuda.device(features.device):
-        check(lib().dance_nchw_to_nhwc(ptr(features), ptr(feat), ptr(att), b, ct, att_channels,
+        check(lib().dance_nchw_to_nhwc(ptr(features), ptr(feat), ptr(att), ptr(words), b, ct, att_channels,
                                        hf * wf, current_stream()), "nchw_to_nhwc")
+    setattr(feat, ABSMAX_ATTR, words)
     return feat, att
 
 
@@ -253,7 +283,9 @@ def pack_conv_weight16(weight, scale=None):
     w = torch.zeros((cout, cin_pad, k), dtype=torch.float32, device=weight.device)
     w[:, :cin, :] = weight.float()
     amax = float(w.abs().max())
-    s = 2.0 ** math.floor(math.log2(1024.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+    s = 1.0
+    if amax > 0 and math.isfinite(amax):        # exponent kept within +-60: 2^s and 2^-s stay plain floats
+        s = 2.0 ** max(-60, min(60, math.floor(math.log2(1024.0 / amax))))
     if scale is not None:               # a slice of a tensor packed elsewhere: that tensor's scale
         s = float(scale)
     ws = w * s
@@ -285,7 +317,7 @@ def from_p16(p):
 
 
 def conv16(x16, w16, scale_pow2, bias, *, cin, cout, v, dilation=1, bn_scale=None, bn_shift=None,
-           residual=False, relu=False, rowinit=None, maxv=False, out_f32=False, mfma_terms=3):
+           residual=False, relu=False, rowinit=None, maxv=False, out_f32=False, mfma_terms=3, residual_mul=1.0):
     """dance_conv16 on a P16 block (N, slots, 2, 16, V, 8); returns P16 (N, cout/128 slots, ...)
     or fp32 (N, cout, V) / (N, cout) with out_f32 / maxv."""
     _need_gpu(x16, w16)
@@ -305,7 +337,8 @@ def conv16(x16, w16, scale_pow2, bias, *, cin, cout, v, dilation=1, bn_scale=Non
         check(lib().dance_conv16(ptr(x16), x16.stride(0), slot, ptr(w16), ptr(bias_s), 1.0 / scale_pow2,
                                  ptr(bn_scale), ptr(bn_shift), ptr(rowinit), int(residual), int(relu),
                                  int(maxv), ptr(y16), 0 if y16 is None else y16.stride(0), slot, ptr(yf),
-                                 yfs, n, v, cin, cout, taps, dilation, mfma_terms, current_stream()), "conv16")
+                                 yfs, float(residual_mul), n, v, cin, cout, taps, dilation, mfma_terms,
+                                 current_stream()), "conv16")
     return yf if y16 is None else y16
 
 
@@ -387,6 +420,7 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
     yb = torch.empty((b, c // 16, h, w, 16), dtype=torch.float32, device=dev)
     stats = torch.empty((b, groups, 2), dtype=torch.float64, device=dev)
     out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
+    words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         st = current_stream()
         to_p16 = lib().dance_nhwc_to_p16img if nhwc_in else lib().dance_nchw_to_p16img
@@ -398,8 +432,10 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
                                          groups, st), "conv3x3_16")
             last = i + 1 == len(layers)
             check(lib().dance_gn_relu(ptr(yb), ptr(stats), ptr(gamma), ptr(beta), eps, groups,
-                                      None if last else ptr(x16), ptr(out) if last else None, b, c, h, w, st),
+                                      None if last else ptr(x16), ptr(out) if last else None,
+                                      ptr(words) if last else None, b, c, h, w, st),
                   "gn_relu")
+    setattr(out, ABSMAX_ATTR, words)
     return out
 
 

@@ -9,15 +9,33 @@ Every arithmetic step runs in libdance_hip.so (see include/dance_hip.h); this fi
 re-lays-out parameters once and enqueues `dance_snake_evolve` per iteration.
 """
 import ctypes
+import math
 import os
 
 import torch
 
 from . import ops
-from ._lib import EVOLVE_EVENTS, SnakeNet16Struct, SnakeNetStruct, check, current_stream, lib, ptr
+from ._lib import EVOLVE_EVENTS, PolicyStruct, SnakeNet16Struct, SnakeNetStruct, check, current_stream, lib, ptr
 
 BN_EPS = 1e-5                          # nn.BatchNorm1d default, snake_head.py:146
 DEFAULT_DILATIONS = (1, 1, 1, 2, 2, 4, 4)   # defaults.py:60-64 / dsnake_head.py:102
+
+
+ACT_TARGET_EXP = 4     # a stored activation's ESTIMATED largest magnitude lands in (2^3, 2^4]: twelve octaves
+                       # of headroom to fp16's 65504 (a worse under-estimate turns into inf -> NaN, loud) and
+                       # seven down to 2^-3, below which a hi/lo pair starts to lose bits (csrc/p16.h) -- with
+                       # an absolute resolution of 2^-25 the pair is then still finer than 2^-28 of the
+                       # block's largest value.  Measured on the synthetic nets (tools/act_range_probe.py):
+                       # DANCE activations sit within 2^2.4 of the estimate; Dsnake's, whose demin
+                       # de_location is in pixels and whose synthetic BatchNorm statistics do not fit it,
+                       # up to 2^7.7 ABOVE -- hence the asymmetric placement.
+
+
+def act_scale_exp(estimate):
+    """a with estimate * 2^a in (2^(ACT_TARGET_EXP - 1), 2^ACT_TARGET_EXP]; 0 for a useless estimate."""
+    if not (estimate > 0 and math.isfinite(estimate)):
+        return 0
+    return max(-40, min(40, ACT_TARGET_EXP - math.ceil(math.log2(estimate))))
 
 
 def _fold_bn(sd, prefix):
@@ -85,54 +103,100 @@ class SnakeNetWeights:
         self._pack16(sdd)
 
     def _pack16(self, sdd):
-        """Split-half (P16) packing for the fast precision mode (dance_snake_evolve16)."""
+        """Split-half (P16) packing for the fast precision mode (dance_snake_evolve16), with the
+        power-of-two activation scales of csrc/p16.h folded into the constants.
+
+        State slot l (l = 0: the head block's output, l + 1: residual block l's) is stored as
+        x * 2^(a_l), prediction[0]'s output as x * 2^(a_p).  The exponents come from estimates
+        of the largest magnitudes: a block's BatchNorm output is bounded by |beta| + 4 |gamma|
+        per channel as long as its running statistics fit the data, the residual stream by the
+        running sum of those bounds; prediction[0]'s output by weight-row norms times the state
+        bounds.  An estimate may be 2^12 too low or 2^7 too high before anything is lost (ACT_TARGET_EXP)."""
         t = self.tensors
         s = SnakeNet16Struct()
         scales = {}
 
-        def pack(name, weight, bias):
+        def pack(name, weight):
             w16, sc = ops.pack_conv_weight16(weight)
             t[name + "_w16"] = w16
             scales[name] = sc
-            if bias is not None:
-                t[name + "_bs"] = (bias * sc).contiguous()
-            return w16.data_ptr(), 1.0 / sc
+            return w16.data_ptr(), sc
 
-        s.head_w, s.head_winv = pack("head", sdd["head.conv.fc.weight"], sdd["head.conv.fc.bias"])
-        s.head_bs = t["head_bs"].data_ptr()
-        # the two de_location input channels of the head block as one 32-deep K step (head16.hip):
-        # k = 0..8 the 9 ring taps of dx, 9..17 of dy, the rest zero; the head's scale
+        def bn_bound(prefix):
+            return float((sdd[prefix + "bias"].abs() + 4.0 * sdd[prefix + "weight"].abs()).max())
+
+        # estimated bound M_l of slot l and its exponent a_l
+        bound, m = [], 0.0
+        for prefix in ["head.norm."] + ["res%d.norm." % i for i in range(7)]:
+            m += bn_bound(prefix)
+            bound.append(m)
+        a = [act_scale_exp(x) for x in bound]
+        p2 = lambda e: 2.0 ** e        # noqa: E731
+
+        # the head block: the feature columns (head_w; the two de_location columns zeroed, they are
+        # not read from this tensor) and the de_location columns (head_wd) at separate scales --
+        # features and de_location values differ in magnitude by whatever the checkpoint says
         hw = sdd["head.conv.fc.weight"]                                           # (128, C + 2, 9)
+        hw_feat = hw.clone()
+        hw_feat[:, -2:, :] = 0
+        s.head_w, sc = pack("head", hw_feat)
+        s.head_winv = 1.0 / sc
+        t["head_bs"] = (sdd["head.conv.fc.bias"] * sc).contiguous()
+        s.head_bs = t["head_bs"].data_ptr()
+        # the two de_location input channels as one 32-deep K step (head16.hip): k = 0..8 the 9 ring
+        # taps of dx, 9..17 of dy, the rest zero
         wd = torch.zeros((hw.shape[0], 32, 1), dtype=torch.float32, device=hw.device)
         wd[:, 0:9, 0] = hw[:, -2, :]
         wd[:, 9:18, 0] = hw[:, -1, :]
-        t["head_wd16"], _ = ops.pack_conv_weight16(wd, scale=scales["head"])
-        s.head_wd = t["head_wd16"].data_ptr()
-        s.head_scale, s.head_shift = t["head_scale"].data_ptr(), t["head_shift"].data_ptr()
+        t["head_wd16"], scd = ops.pack_conv_weight16(wd)
+        scales["head_wd"] = scd
+        s.head_wd, s.head_wd_winv = t["head_wd16"].data_ptr(), 1.0 / scd
+        t["head_scale16"] = (t["head_scale"] * p2(a[0])).contiguous()
+        t["head_shift16"] = (t["head_shift"] * p2(a[0])).contiguous()
+        s.head_scale, s.head_shift = t["head_scale16"].data_ptr(), t["head_shift16"].data_ptr()
         for i in range(7):
             n = "res%d" % i
-            s.res_w[i], s.res_winv[i] = pack(n, sdd[n + ".conv.fc.weight"], sdd[n + ".conv.fc.bias"])
+            s.res_w[i], sc = pack(n, sdd[n + ".conv.fc.weight"])
+            s.res_winv[i] = p2(-a[i]) / sc
+            s.res_rmul[i] = p2(a[i + 1] - a[i])
+            t[n + "_bs"] = (sdd[n + ".conv.fc.bias"] * (sc * p2(a[i]))).contiguous()
+            t[n + "_scale16"] = (t[n + "_scale"] * p2(a[i + 1])).contiguous()
+            t[n + "_shift16"] = (t[n + "_shift"] * p2(a[i + 1])).contiguous()
             s.res_bs[i] = t[n + "_bs"].data_ptr()
-            s.res_scale[i], s.res_shift[i] = t[n + "_scale"].data_ptr(), t[n + "_shift"].data_ptr()
+            s.res_scale[i], s.res_shift[i] = t[n + "_scale16"].data_ptr(), t[n + "_shift16"].data_ptr()
             s.dilation[i] = self.dilations[i]
-        # fusion and the state columns of prediction[0] as ONE 512-output GEMM (common scale)
+        # fusion and the state columns of prediction[0] as ONE 512-output GEMM over the 8 slots: the
+        # columns of slot j divided by 2^(a_j), each half of the rows packed with its own scale
+        col = torch.tensor([p2(-a[j]) for j in range(8)], dtype=torch.float32,
+                           device=hw.device).repeat_interleave(128)[None, :, None]
         p0 = sdd["prediction.0.weight"]
-        both = torch.cat([sdd["fusion.weight"], p0[:, 256:, :]], dim=0)          # (512, 1024, 1)
-        fb = torch.cat([sdd["fusion.bias"], torch.zeros_like(sdd["fusion.bias"])])
-        s.fuse_w, s.fuse_winv = pack("fuse", both, fb)
+        wf, wp = sdd["fusion.weight"], p0[:, 256:, :]
+        f16, sf = ops.pack_conv_weight16(wf * col)
+        p16, sp = ops.pack_conv_weight16(wp * col)
+        t["fuse_w16"] = torch.cat([f16, p16], dim=3).contiguous()                 # (2,1,128,512,8)
+        scales["fuse"], scales["pred0"] = sf, sp
+        s.fuse_w = t["fuse_w16"].data_ptr()
+        t["fuse_bs"] = torch.cat([sdd["fusion.bias"] * sf, torch.zeros_like(sdd["fusion.bias"])]).contiguous()
         s.fuse_bs = t["fuse_bs"].data_ptr()
-        w16 = t["fuse_w16"]                                                       # (2,1,128,512,8)
-        t["fuse_split_w16"] = w16[:, :, :, :256].contiguous()
-        t["pred0_split_w16"] = w16[:, :, :, 256:].contiguous()
-        s.fuse_w_split = t["fuse_split_w16"].data_ptr()
-        s.pred0_w_split = t["pred0_split_w16"].data_ptr()
-        s.pred0_wg, s.pred0_b = t["pred0_wg"].data_ptr(), t["pred0_b"].data_ptr()
-        s.pred1_w, s.pred1_winv = pack("pred1", sdd["prediction.2.weight"], sdd["prediction.2.bias"])
+        # prediction[0]'s output scale: |state part| + |row constant|, from row norms and the slot bounds
+        mb = torch.tensor(bound, dtype=torch.float32, device=hw.device)
+        row = lambda w: float(((w[:, :, 0].reshape(w.shape[0], 8, 128) ** 2).sum(2) * mb[None] ** 2).sum(1).sqrt().max())  # noqa: E731
+        g_bound = float(sdd["fusion.bias"].abs().max()) + row(wf)
+        h_bound = float(sdd["prediction.0.bias"].abs().max()) + float((t["pred0_wg"] ** 2).sum(0).sqrt().max()) * g_bound
+        ap = act_scale_exp(row(wp) + h_bound)
+        s.fuse_winv, s.pred0_winv = 1.0 / sf, p2(ap) / sp
+        t["pred0_wg16"] = (t["pred0_wg"] * p2(ap)).contiguous()
+        t["pred0_b16"] = (t["pred0_b"] * p2(ap)).contiguous()
+        s.pred0_wg, s.pred0_b = t["pred0_wg16"].data_ptr(), t["pred0_b16"].data_ptr()
+        s.pred1_w, sc = pack("pred1", sdd["prediction.2.weight"])
+        s.pred1_winv = p2(-ap) / sc
+        t["pred1_bs"] = (sdd["prediction.2.bias"] * (sc * p2(ap))).contiguous()
         s.pred1_bs = t["pred1_bs"].data_ptr()
         s.pred2_w, s.pred2_b = t["pred2_w"].data_ptr(), t["pred2_b"].data_ptr()
         s.feat_channels = self.feature_dim - 2
         self.struct16 = s
         self.scales16 = scales
+        self.act_exps = {"slots": a, "pred0": ap, "bounds": bound}
 
 
 def sub_state_dict(sd, prefix):
@@ -181,6 +245,7 @@ class ContourDeformer:
         self.individual_scale = bool(individual_scale)
         self.attention = bool(attention)
         self.fused_head = bool(fused_head)
+        self.policy = PolicyStruct()         # kernel-form choices of the fast mode (include/dance_hip.h dance_policy)
         self._ws = None
 
     def _workspace(self, n, v, device):
@@ -208,6 +273,7 @@ class ContourDeformer:
         parts = []
         for i, (st, d) in enumerate(self._side):
             d.MAX_CHUNK = self.MAX_CHUNK
+            d.policy = self.policy
             d._no_peel = True                    # a part of a split batch is not split again
             st.wait_stream(cur)
             with torch.cuda.stream(st):
@@ -251,11 +317,13 @@ class ContourDeformer:
                                                self.attention, self.fused_head, self.precision))
         st, side = self._peel_side
         side._no_peel = True
+        side.policy = self.policy
         locations = init_contours.contiguous().float()
         whs = None if whs is None else whs.contiguous().float()
         idx = image_idx.to(torch.int32).contiguous()
         preds = [torch.empty((n, v, 2), dtype=torch.float32, device=dev) for _ in self.nets]
         feat, att = feat_att
+        absmax = self._absmax(feat)              # measured once (here, if the tensor does not carry it) for both chains
         st.wait_stream(cur)                      # features, inputs and the output buffers exist
         for d, lo, hi, stream, ev in ((side, m, n, st, None), (self, 0, m, cur, stage_events)):
             with torch.cuda.stream(stream):
@@ -263,16 +331,25 @@ class ContourDeformer:
                 for i in range(len(self.nets)):
                     prev = d.evolve(i, feat, att, prev, idx[lo:hi], None if whs is None else whs[lo:hi],
                                     use_att=(self.attention and i > 0), clip_first=False, clip_max=(0.0, 0.0),
-                                    out=preds[i][lo:hi], stage_events=None if ev is None else ev[i])
+                                    out=preds[i][lo:hi], stage_events=None if ev is None else ev[i], absmax=absmax)
         cur.wait_stream(st)                      # everything the side stream touched is ordered before what follows
         return preds
 
+    def _fast(self, c, x_in=None):
+        """Does an iteration on c feature channels run the split-half kernels?"""
+        return self.precision in ("fp16x3", "fp16") and x_in is None and c % 64 == 0
+
+    def _absmax(self, feat):
+        """The features' per-image max words for the fast mode's head block (ops.absmax_of), or None."""
+        return ops.absmax_of(feat) if self._fast(feat.shape[-1]) else None
+
     def evolve(self, it, feat, att, locations, image_idx, whs, *, use_att, clip_first, clip_max,
-               x_in=None, out=None, stage_events=None):
+               x_in=None, out=None, stage_events=None, absmax=None):
         """One iteration with deformer `it` (RefineNet.evolve, snake_head.py:1624-1713).
         stage_events: optional list of EVOLVE_EVENTS recorded torch.cuda.Event(enable_timing),
         entries may be None (boundary not timed)
-        (single-chunk calls only) -- bench instrumentation."""
+        (single-chunk calls only) -- bench instrumentation.
+        absmax: `ops.absmax_of(feat)` when the caller already holds it (fast mode only)."""
         net = self.nets[it]
         n, v, _ = locations.shape
         dev = locations.device
@@ -295,30 +372,36 @@ class ContourDeformer:
             if n > chunk or len(stage_events) != EVOLVE_EVENTS:
                 raise RuntimeError("stage events need a single-chunk call and %d events" % EVOLVE_EVENTS)
             ev = (ctypes.c_void_p * EVOLVE_EVENTS)(*[None if e is None else e.cuda_event for e in stage_events])
+        fast = self._fast(c, x_in)               # else exact fp32: precision="fp32", a precomputed input, odd widths
+        if self.precision == "fp16" and x_in is None and not fast:
+            raise RuntimeError("precision 'fp16' needs feature channels % 64 == 0")
+        terms = 1 if self.precision == "fp16" else 3
+        if fast and absmax is None:
+            absmax = ops.absmax_of(feat)
         with torch.cuda.device(dev):
             stream = current_stream()
             for n0 in range(0, n, chunk):
                 nb = min(chunk, n - n0)
-                args16 = ()
-                fn = lib().dance_snake_evolve
-                fast = self.precision in ("fp16x3", "fp16") and c % 64 == 0
-                if self.precision == "fp16" and not fast:
-                    raise RuntimeError("precision 'fp16' needs feature channels % 64 == 0")
+                idx_p = ptr(image_idx[n0:]) if image_idx is not None else None
+                whs_p = ptr(whs[n0:]) if whs is not None else None
                 if fast:
-                    fn = lib().dance_snake_evolve16
-                    args16 = (ctypes.byref(net.struct16),)
-                check(fn(
-                    *args16, ctypes.byref(net.struct), ptr(feat), ptr(att), ptr(locations[n0:]),
-                    ptr(image_idx[n0:]) if image_idx is not None else None,
-                    ptr(whs[n0:]) if whs is not None else None,
-                    ptr(x_in[n0:]) if x_in is not None else None, ptr(out[n0:]), ptr(ws), need,
-                    nb, v, b, hf, wf, self.padding, self.deloc, int(self.individual_scale),
-                    int(use_att), int(clip_first and n0 == 0), float(clip_max[0]), float(clip_max[1]),
-                    *((1 if self.precision == "fp16" else 3,) if fast else (int(self.fused_head),)),
-                    ev, stream), "snake_evolve")
+                    check(lib().dance_snake_evolve16(
+                        ctypes.byref(net.struct16), ptr(feat), ptr(att), ptr(absmax), ptr(locations[n0:]), idx_p,
+                        whs_p, ptr(out[n0:]), ptr(ws), need, nb, v, b, hf, wf, self.padding, self.deloc,
+                        int(self.individual_scale), int(use_att), int(clip_first and n0 == 0),
+                        float(clip_max[0]), float(clip_max[1]), terms, ctypes.byref(self.policy), ev, stream),
+                        "snake_evolve16")
+                else:
+                    # exact fp32 (precision="fp32", a precomputed input x_in, odd channel counts)
+                    check(lib().dance_snake_evolve(
+                        ctypes.byref(net.struct), ptr(feat), ptr(att), ptr(locations[n0:]), idx_p, whs_p,
+                        ptr(x_in[n0:]) if x_in is not None else None, ptr(out[n0:]), ptr(ws), need,
+                        nb, v, b, hf, wf, self.padding, self.deloc, int(self.individual_scale),
+                        int(use_att), int(clip_first and n0 == 0), float(clip_max[0]), float(clip_max[1]),
+                        int(self.fused_head), ev, stream), "snake_evolve")
         return out
 
-    def init_evolve(self, it, feat, locations, image_idx, fuse, out=None, stage_events=None):
+    def init_evolve(self, it, feat, locations, image_idx, fuse, out=None, stage_events=None, absmax=None):
         """Dsnake's init stage (DsnakeHead.init, dsnake_head.py:718-744) with deformer `it` in one
         kernel sequence of the fast precision mode: gather + centre feature + `fuse` +
         de_location + head block in one launch, then stack / fusion / tail.  fuse: InitFuse16Struct
@@ -344,6 +427,8 @@ class ContourDeformer:
             if n > chunk or len(stage_events) != EVOLVE_EVENTS:
                 raise RuntimeError("stage events need a single-chunk call and %d events" % EVOLVE_EVENTS)
             ev = (ctypes.c_void_p * EVOLVE_EVENTS)(*[None if e is None else e.cuda_event for e in stage_events])
+        if absmax is None:
+            absmax = ops.absmax_of(feat)
         with torch.cuda.device(dev):
             stream = current_stream()
             for n0 in range(0, n, chunk):
@@ -352,7 +437,7 @@ class ContourDeformer:
                     ctypes.byref(net.struct16), ctypes.byref(fuse), ptr(feat), ptr(locations[n0:]),
                     ptr(image_idx[n0:]) if image_idx is not None else None, ptr(out[n0:]), ptr(ws), need,
                     nb, v, b, hf, wf, self.padding, self.deloc, 1 if self.precision == "fp16" else 3,
-                    ev, stream), "snake_init16")
+                    ptr(absmax), ctypes.byref(self.policy), ev, stream), "snake_init16")
         return out
 
     def supports_init_evolve(self, c, v):
@@ -375,6 +460,12 @@ class ContourDeformer:
         (all iterations) on its own HIP stream -- contours are independent, so one part's kernel
         tails and launch gaps overlap the other's kernels (measured: 2 streams -4 % wall on
         config 2; results bit-identical)."""
+        if layout == "nhwc" and self._fast(features[0].shape[-1]) and getattr(features[0], ops.ABSMAX_ATTR, None) is None:
+            # an NHWC tensor from elsewhere: measure its per-image maxima once for this call and hand them
+            # down on a private view (nothing is cached on the caller's tensor, which may change in place)
+            feat = features[0].view(features[0].shape)
+            setattr(feat, ops.ABSMAX_ATTR, ops.feature_absmax(features[0]))
+            features = (feat, features[1])
         if streams > 1 and init_contours.size(0) >= 2 * streams and stage_events is None and image_idx is not None:
             return self._deform_streams(features, init_contours, image_idx, image_sizes, whs, layout, streams)
         side_n = self.peel_count(init_contours.size(0), init_contours.device) if image_idx is not None else 0
@@ -393,10 +484,11 @@ class ContourDeformer:
             idx = image_idx.to(torch.int32).contiguous()
         clip_first = image_idx is None
         clip_max = (image_sizes[1] - 1, image_sizes[0] - 1) if clip_first else (0.0, 0.0)
+        absmax = self._absmax(feat)
         preds, cur = [], locations
         for i in range(len(self.nets)):
             cur = self.evolve(i, feat, att, cur, idx, whs, use_att=(self.attention and i > 0),
                               clip_first=clip_first, clip_max=clip_max,
-                              stage_events=None if stage_events is None else stage_events[i])
+                              stage_events=None if stage_events is None else stage_events[i], absmax=absmax)
             preds.append(cur)
         return preds

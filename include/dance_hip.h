@@ -29,6 +29,26 @@ const char *dance_last_error(void);          /* thread-local text of the last fa
 /* Fills CU count and LDS bytes per workgroup of the current device (host out-params). */
 int dance_device_info(int *cu_count_host, int *lds_bytes_host);
 
+/* How the fast-mode entry points pick among kernel forms that give identical results.  Passed by
+ * pointer per call (NULL = the defaults below): the library holds no process-global switches and
+ * reads no environment variables.
+ *   few_contour_forms  1: batches with fewer contours than CUs (the reference's one-image
+ *                      inference, ~100 instances on 256 CUs) run forms that spread a contour over
+ *                      more hardware: half-ring head workgroups (n <= DANCE_FEW_HEAD, 65..128
+ *                      vertices), the 8-wave residual stack (n <= DANCE_FEW_STACK, 97..128), two
+ *                      fusion parts (n <= DANCE_FEW_FUSE, 97..128); 0: never.  Bit-identical.
+ *   fuse_tail_split    1: the fusion kernel runs the contours of a mostly empty last round of
+ *                      workgroups as half rings (dance_fuse16w_tail_split); 0: never.  Bit-identical.
+ *   tail_group         contours per workgroup of dance_tail16: 1, 2 or 4; 0 = by batch size. */
+typedef struct dance_policy {
+    int few_contour_forms;
+    int fuse_tail_split;
+    int tail_group;
+} dance_policy;
+#define DANCE_FEW_HEAD 128
+#define DANCE_FEW_STACK 256
+#define DANCE_FEW_FUSE 128
+
 /* ------------------------------------------------------- extreme_utils (L6) -------- */
 /* reference: core/layers/extreme_utils/src/utils.cu:114-212 (pybind `collect_extreme_point`,
  * utils.cpp:5).  ext_hm (b,4,h,w) f32, bbox (b,n,4) i64, radius (b,n) i64,
@@ -136,10 +156,11 @@ int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_scale, float 
                      void *stream);
 /* dance_gn_relu: GroupNorm(groups, eps) * gamma + beta, then ReLU, of y_blocked using stats;
  *   exactly one of out16 (P16 image, the next layer's input) / out_nhwc ((b, h, w, c) fp32,
- *   what the gather kernels read) is non-null. */
+ *   what the gather kernels read) is non-null.  absmax (with out_nhwc; may be NULL): the
+ *   per-image max |output| words of dance_nchw_to_nhwc, measured on the way out. */
 int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamma,
                   const float *beta, float eps, int groups, void *out16, float *out_nhwc,
-                  int b, int c, int h, int w, void *stream);
+                  uint32_t *absmax, int b, int c, int h, int w, void *stream);
 
 /* ------------------------------------ attention-map producer ------ */
 /* reference: EdgeSnakeFPNHead.attender, core/modeling/edge_snake/edge_det.py:66-100, applied
@@ -297,9 +318,15 @@ int dance_octagon_upsample(const float *ext_points, int64_t poly_stride, int64_t
 /* ----------------------------------------------------------------- layout ---------- */
 /* (b, c_total, hw) NCHW -> feat (b, hw, c_total - att_channels) NHWC and, when
  * att_channels == 1, channel 0 -> att (b, hw).  Replaces the split at
- * snake_head.py:1812-1814 / 1949-1951 plus the layout change the gather wants. */
-int dance_nchw_to_nhwc(const float *src, float *feat, float *att, int b, int c_total,
-                       int att_channels, int hw, void *stream);
+ * snake_head.py:1812-1814 / 1949-1951 plus the layout change the gather wants.
+ * absmax (b, DANCE_ABSMAX_WORDS) u32 or NULL: per image, partial maxima of |feature| as float bit
+ * patterns (zeroed here on the stream, then raised by atomic max -- order-independent, hence
+ * deterministic); the fast mode's head block scales its input by them (dance_snake_evolve16). */
+#define DANCE_ABSMAX_WORDS 8
+int dance_nchw_to_nhwc(const float *src, float *feat, float *att, uint32_t *absmax, int b,
+                       int c_total, int att_channels, int hw, void *stream);
+/* The same words for an NHWC feature tensor that arrives from elsewhere: feat (b, per_image floats). */
+int dance_feature_absmax(const float *feat, int b, int64_t per_image, uint32_t *absmax, void *stream);
 
 /* ------------------------------------------------------------ gather (a1-a3) ------- */
 enum { DANCE_PAD_ZEROS = 0, DANCE_PAD_REFLECTION = 1 };
@@ -411,8 +438,16 @@ int dance_snake_evolve(const dance_snake_net *net_host, const float *feat, const
 /* ------------------------------------------------ fast precision mode (P16) ------- *
  * Activations and weights as fp16 hi/lo pairs (22 significant bits), every product as three
  * f16 MFMAs accumulated in fp32: fp32-level accuracy at 16/3 of the fp32-MFMA rate
- * (dance_amd/csrc/p16.h has the format).  Values beyond the fp16 range (|x| >= 65504) turn
- * into NaN -- loud, never silently wrong; dance_snake_evolve stays the exact-fp32 path.
+ * (dance_amd/csrc/p16.h has the format).  dance_snake_evolve stays the exact-fp32 path.
+ *
+ * Range.  A pair carries its 22 bits while 2^-3 <= |x| < 65504 and degrades gracefully below
+ * (absolute resolution 2^-25); beyond 65504 it is inf and surfaces as NaN coordinates -- loud,
+ * never silently wrong.  Everything that is split is therefore first multiplied by a power of
+ * two that is undone exactly where the fp32 accumulator is read: the head block's input by a
+ * per-contour factor from the image's measured max |feature| (absmax words) and the contour's
+ * de_location range; the state slots and prediction[0]'s output by per-net factors fixed when
+ * the weights are packed (dance_amd/snake.py: from the BatchNorm parameters / weight norms), which
+ * arrive folded into the constants of dance_snake_net16.
  *
  * P16 block of C channels (C % 128 == 0 or C <= 128; always slots of 128):
  *   [slot][plane hi/lo][c/8][v][8] halfs, slot stride given by the caller.
@@ -423,128 +458,100 @@ int dance_snake_evolve(const dance_snake_net *net_host, const float *feat, const
  * operands, fp32 accumulate: one third of the MFMAs, ~1e-2 coordinate error -- the
  * approximate "half precision" variant of BASELINE config 2, never the default).            */
 
-/* Same op as dance_circconv on P16 input.  Output either P16 (y16) or fp32 channel-major
- * (y_f32); residual != 0 adds the input itself (needs cin == cout <= 128); rowinit (n,cout)
+/* One SnakeBlock / k=1 Conv1d on P16 input (the single-block form; dance_res_stack16 is what
+ * dance_snake_evolve16 runs).  Output either P16 (y16) or fp32 channel-major (y_f32);
+ * residual != 0 adds the input itself times residual_mul (a power of two: 1 when input and
+ * output are stored at the same activation scale; needs cin == cout <= 128); rowinit (n,cout)
  * replaces the bias as accumulator start; maxv != 0 writes max over the ring to y_f32 (n,cout).
  * reference: SnakeBlock snake_head.py:140-153 + residual :266; k=1 Conv1d :252-258. */
 int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
                  const float *bias_scaled, float w_inv_scale, const float *scale,
                  const float *shift, const float *rowinit, int residual, int relu, int maxv,
                  void *y16, int64_t y_stride, int64_t y_slot_stride, float *y_f32,
-                 int64_t yf_stride, int n, int v, int cin, int cout, int taps, int dilation,
-                 int mfma_terms, void *stream);
+                 int64_t yf_stride, float residual_mul, int n, int v, int cin, int cout, int taps,
+                 int dilation, int mfma_terms, void *stream);
 
-/* fusion Conv1d + max over the ring + row constant + prediction[0] in one pass over the
- * (n, 1024, v) P16 state.  w16 packs fusion.weight (outputs 0..255) and the 1024 state
- * columns of prediction[0] (outputs 256..511) as one 512-output GEMM; bias_scaled (512) =
- * fusion bias * 2^s then zeros; wg (256,256) [g][o] fp32 = prediction[0]'s global-state
- * columns; pred_bias (256).  Output: relu(prediction[0]) as a 2-slot P16 block.  v <= 128
- * (larger rings run the same stages as three dance_conv16 / dance_row_constant launches).
- * reference: _SnakeNet.forward snake_head.py:269-282. */
-int dance_fuse16(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
-                 const float *bias_scaled, float w_inv_scale, const float *wg,
-                 const float *pred_bias, void *y16, int64_t y_stride, int64_t y_slot_stride, int n,
-                 int v, int mfma_terms, void *stream);
-
-/* The raw form of dance_fuse16 for any ring up to 256 vertices: the same 512-output GEMM, but the
- * kernel stops before the row constant.  Both convolutions are pointwise over the ring, so rings
- * above 128 vertices are split into dance_fuse16_parts(n, v) parts (2 above 128 vertices, and for at most 128 contours of
- * 97..128 vertices: one image's instances then keep two CUs each busy), one workgroup each.  Outputs:
- * gpart (n, parts, 256) f32 = max of the fusion output over each part's vertices, and y16 (2-slot
- * P16) = the 1024 state columns of prediction[0] applied to the state, WITHOUT bias / row constant
- * / ReLU.  dance_tail16 takes both.  reference: _SnakeNet.forward snake_head.py:269-278. */
-int dance_fuse16_parts(int n, int v);
-int dance_fuse16_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
-                     const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
-                     int64_t y_slot_stride, float *gpart, int n, int v, int mfma_terms, void *stream);
-
-/* dance_fuse16_raw on 16-wide vertex tiles (v_mfma_f32_16x16x32_f16; csrc/fuse16w.hip): same
- * inputs, outputs and `parts` meaning (dance_fuse16w_supported(parts, v): one part for 16..128
- * vertices, two for 97..256): a part runs ceil(vertices / 16) column tiles rounded up to an
- * instantiated count -- 196 vertices as 7 + 6 tiles = 208 columns instead of 224, 40 as 3 = 48
- * instead of 64.  Same products per output element in another summation order; the default fusion
- * kernel of dance_snake_evolve16 (DANCE_FUSE16_SHAPE=32 restores dance_fuse16_raw).
- * reference: _SnakeNet.forward snake_head.py:269-278. */
+/* fusion Conv1d + max over the ring, and the 1024 state columns of prediction[0], in one pass over
+ * the (n, 1024, v) P16 state (csrc/fuse16w.hip, v_mfma_f32_16x16x32_f16, 16-wide vertex tiles).
+ * w16 packs fusion.weight (outputs 0..255, inverse scale w_inv_scale) and prediction[0]'s state
+ * columns (outputs 256..511, pred_w_inv_scale -- which also carries the scale the stored block
+ * is kept at) as one 512-output GEMM; bias_scaled (512) = fusion bias * 2^s, then zeros.
+ * Both convolutions are pointwise over the ring, so a ring runs as `parts` workgroups
+ * (dance_fuse16_parts: 2 above 128 vertices and, for few contours, from 97; dance_fuse16w_supported
+ * (parts, v): one part for 16..128 vertices, two for 97..256), a part as ceil(vertices / 16) column
+ * tiles rounded up to an instantiated count.  Outputs: gpart (n, parts, 256) f32 = max of the fusion
+ * output over each part's vertices, and y16 (2-slot P16) = prediction[0]'s state part WITHOUT bias /
+ * row constant / ReLU.  dance_tail16 takes both.  reference: _SnakeNet.forward snake_head.py:269-278. */
+int dance_fuse16_parts(int n, int v, const dance_policy *policy);
 int dance_fuse16w_supported(int parts, int v);
 int dance_fuse16w_raw(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
-                      const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
-                      int64_t y_slot_stride, float *gpart, int n, int v, int parts, int mfma_terms,
-                      void *stream);
+                      const float *bias_scaled, float w_inv_scale, float pred_w_inv_scale, void *y16,
+                      int64_t y_stride, int64_t y_slot_stride, float *gpart, int n, int v, int parts,
+                      int mfma_terms, void *stream);
 
 /* dance_fuse16w_raw for rings of 97..128 vertices whose LAST n_split contours run as two half-ring
  * workgroups each: the kernel holds one workgroup per CU, so n contours take ceil(n / CUs) rounds and
  * the last round of n mod CUs workgroups costs as much as a full one (1600 contours on 256 CUs: 6.25
  * -> 7 rounds); as half rings it takes about half as long on twice the CUs.  gpart2 is (n, 2, 256):
  * whole rings write their max to both part slots, so dance_tail16 is called with parts = 2.
- * dance_fuse16w_tail_split(n, v): the n_split dance_snake_evolve16 uses -- n mod CUs when there is more
- * than one round and that remainder fills at most half the CUs, else 0 (DANCE_FUSE16_TAIL_SPLIT=0:
- * always 0).  Outputs bit-identical to dance_fuse16w_raw with one part (same products, same
- * order; the max over a ring is the max of its halves' maxima).  reference: as dance_fuse16w_raw. */
-int dance_fuse16w_tail_split(int n, int v);
+ * dance_fuse16w_tail_split(n, v, policy): the n_split dance_snake_evolve16 uses -- n mod CUs when there
+ * is more than one round and that remainder fills at most half the CUs, else 0.  Outputs bit-identical
+ * to dance_fuse16w_raw with one part (same products, same order; the max over a ring is the max of its
+ * halves' maxima).  reference: as dance_fuse16w_raw. */
+int dance_fuse16w_tail_split(int n, int v, const dance_policy *policy);
 int dance_fuse16w_raw_split(const void *x, int64_t x_stride, int64_t x_slot_stride, const void *w16,
-                            const float *bias_scaled, float w_inv_scale, void *y16, int64_t y_stride,
-                            int64_t y_slot_stride, float *gpart2, int n, int v, int n_split,
-                            int mfma_terms, void *stream);
+                            const float *bias_scaled, float w_inv_scale, float pred_w_inv_scale,
+                            void *y16, int64_t y_stride, int64_t y_slot_stride, float *gpart2, int n,
+                            int v, int n_split, int mfma_terms, void *stream);
 
 /* The end of a _SnakeNet and of evolve in one launch: global state = max over gpart's parts ->
  * row constant h = pred0_bias + wg^T g (as dance_row_constant) -> relu(p1 + h) -> prediction[2]
  * (w1_16: packed (2,1,32,64,8), b1_scaled, w1_inv_scale) + ReLU -> prediction[4] + offset update
  * exactly as dance_offset_update (same arguments).  The (n,64,v) block between the last two
- * stays on chip.  reference: snake_head.py:272-282 (row constant, prediction), 1702-1727. */
+ * stays on chip.  When p1 is kept at a power-of-two scale 2^a, wg / pred0_bias / b1_scaled arrive
+ * multiplied and w1_inv_scale divided by it (dance_snake_net16).
+ * reference: snake_head.py:272-282 (row constant, prediction), 1702-1727. */
 int dance_tail16(const void *p1, int64_t p1_stride, int64_t p1_slot_stride, const float *gpart,
                  int parts, const float *wg, const float *pred0_bias, const void *w1_16,
                  const float *b1_scaled, float w1_inv_scale, const float *w3, const float *b3,
                  const float *loc, const float *whs, const float *att, float *out, int n, int v,
-                 int clip_first, float clip_x_max, float clip_y_max, int mfma_terms, void *stream);
+                 int clip_first, float clip_x_max, float clip_y_max, int mfma_terms,
+                 const dance_policy *policy, void *stream);
 
-/* Fused gather + de_location + head SnakeBlock writing slot 0 of a P16 block
- * (as dance_gather_circconv_head; c % 64 == 0).  wd16: the two de_location channels as one K step
- * (dance_snake_net16.head_wd), or null: they ride a zero-padded 32-channel chunk through the 9 ring
- * taps (w16's last channel blocks). */
-int dance_gather_head16(const float *feat, const float *att, const float *loc,
-                        const int32_t *image_idx, const void *w16, const void *wd16,
-                        const float *bias_scaled,
-                        float w_inv_scale, const float *scale, const float *shift, void *y16,
-                        int64_t y_stride, float *att_out, int n, int v, int b, int hf, int wf, int c,
-                        int padding_mode, int deloc_type, int mfma_terms, void *stream);
-
-/* dance_gather_head16 on 16-wide vertex tiles (v_mfma_f32_16x16x32_f16): the ring is padded to a
- * multiple of 16 columns instead of 32 (196 vertices: 208 instead of 224), and the two de_location
- * channels are one K step (wd16, see dance_snake_net16.head_wd) instead of a zero-padded chunk
- * through all 9 ring taps.  Rings above DANCE_HEAD16W_MAX_V vertices run as two half
- * rings in two workgroups, each with 4 halo vertices either side (DANCE_HEAD_HALVES=0: handed to
- * dance_gather_head16 with wd16).  Same results up to summation order.  reference: as dance_gather_head16
- * (snake_head.py:1542-1572, 1587-1610, 1639-1652, _SnakeNet.head :233). */
+/* Fused gather + de_location + head SnakeBlock writing slot 0 of a P16 block (as
+ * dance_gather_circconv_head; c % 64 == 0) on v_mfma_f32_16x16x32_f16: the ring is padded to a
+ * multiple of 16 columns (196 vertices: 208), and the two de_location channels are one K step
+ * (wd16, see dance_snake_net16.head_wd) instead of a zero-padded chunk through all 9 ring taps.
+ * Rings above 128 vertices (and 65..128-vertex rings of few contours) run as two half rings in two
+ * workgroups, each with 4 halo vertices either side.  feat_absmax (b, DANCE_ABSMAX_WORDS) or NULL:
+ * the input is split at a per-contour power-of-two scale (see "Range" above); NULL = unscaled.
+ * reference: snake_head.py:1542-1572, 1587-1610, 1639-1652, _SnakeNet.head :233. */
 #define DANCE_HEAD16W_MAX_V 208
 int dance_gather_head16w(const float *feat, const float *att, const float *loc,
                          const int32_t *image_idx, const void *w16, const void *wd16,
-                         const float *bias_scaled, float w_inv_scale, const float *scale,
-                         const float *shift, void *y16, int64_t y_stride, float *att_out, int n, int v,
-                         int b, int hf, int wf, int c, int padding_mode, int deloc_type, int mfma_terms,
-                         void *stream);
-
-/* The same head block on a precomputed fp32 input x_in (n, c + 2, v), contour stride x_stride
- * floats, instead of the gather: DsnakeHead.init's input, the fused [sampled | centre] features
- * plus the two de_location channels (dsnake_head.py:718-741). */
-int dance_xin_head16(const float *x_in, int64_t x_stride, const void *w16, const float *bias_scaled,
-                     float w_inv_scale, const float *scale, const float *shift, void *y16,
-                     int64_t y_stride, int n, int v, int c, int mfma_terms, void *stream);
+                         const float *bias_scaled, float w_inv_scale, float wd_inv_scale,
+                         const float *scale, const float *shift, void *y16, int64_t y_stride,
+                         float *att_out, int n, int v, int b, int hf, int wf, int c, int padding_mode,
+                         int deloc_type, int mfma_terms, const uint32_t *feat_absmax,
+                         const dance_policy *policy, void *stream);
 
 /* Dsnake's init stage up to the init snake's head block in one launch (c = 256, 16 <= v <= 64):
  * bilinear gather at the ring's vertices and at its centre (min + max) / 2, fuse Conv1d(2c -> c,
  * k = 1) with the centre half folded into a per-contour row constant (fuse_w16: the sampled half
  * packed (2,1,32,256,8) with inverse scale fuse_w_inv_scale; fuse_wg: the centre half as [g][o]
  * (256,256) fp32; fuse_bias (256)), de_location, head SnakeBlock on 16-wide vertex tiles (head_w16 /
- * head_wd16 as in dance_gather_head16w) -> slot 0 of a P16 block.
+ * head_wd16 as in dance_gather_head16w) -> slot 0 of a P16 block.  The gathered features are split
+ * at the image's scale (feat_absmax, may be NULL), the fused block at its own measured maximum.
  * reference: DsnakeHead.init dsnake_head.py:718-736 (+ get_locations_feature :678-695,
  * de_location :697-708, _SnakeNet.head :99, :120). */
 int dance_init_head16(const float *feat, const float *loc, const int32_t *image_idx,
                       const void *fuse_w16, float fuse_w_inv_scale, const float *fuse_wg,
                       const float *fuse_bias, const void *head_w16, const void *head_wd16,
-                      const float *head_bias_scaled,
-                      float head_w_inv_scale, const float *head_scale, const float *head_shift,
+                      const float *head_bias_scaled, float head_w_inv_scale,
+                      float head_wd_inv_scale, const float *head_scale, const float *head_shift,
                       void *y16, int64_t y_stride, int n, int v, int b, int hf, int wf, int c,
-                      int padding_mode, int deloc_type, int mfma_terms, void *stream);
+                      int padding_mode, int deloc_type, int mfma_terms, const uint32_t *feat_absmax,
+                      void *stream);
 
 /* DsnakeHead.fuse (dsnake_head.py:242, Conv1d(2c, c, 1)) packed for dance_init_head16. */
 typedef struct dance_init_fuse16 {
@@ -554,52 +561,51 @@ typedef struct dance_init_fuse16 {
     float w_inv_scale;
 } dance_init_fuse16;
 
+/* One _SnakeNet packed for the fast mode (dance_amd/snake.py SnakeNetWeights._pack16).  With the
+ * state slot l kept at scale 2^(a_l) and prediction[0]'s output at 2^(a_p):
+ *   head_scale / head_shift = folded BatchNorm * 2^(a_0);
+ *   res_bs[l] = bias * 2^(s_l + a_l), res_winv[l] = 2^-(s_l + a_l), res_scale / res_shift[l] =
+ *   folded BatchNorm * 2^(a_(l+1)), res_rmul[l] = 2^(a_(l+1) - a_l);
+ *   fuse_w: column block j of both halves divided by 2^(a_j) before packing; fuse_winv = 2^-s,
+ *   pred0_winv = 2^(a_p - s'); pred0_wg / pred0_b multiplied by 2^(a_p);
+ *   pred1_bs = bias * 2^(s + a_p), pred1_winv = 2^-(s + a_p). */
 typedef struct dance_snake_net16 {
     const void *head_w;  const float *head_bs, *head_scale, *head_shift;
     const void *res_w[7]; const float *res_bs[7], *res_scale[7], *res_shift[7];
     const void *fuse_w;  const float *fuse_bs, *pred0_wg, *pred0_b;   /* fuse_w: (2,1,128,512,8) */
-    const void *fuse_w_split, *pred0_w_split;     /* the two 256-output halves of fuse_w, packed
-                                                     separately (2,1,128,256,8): rings > 128 */
     const void *pred1_w; const float *pred1_bs;
     const float *pred2_w, *pred2_b;
-    float head_winv, res_winv[7], fuse_winv, pred1_winv;
+    float head_winv, res_winv[7], res_rmul[7], fuse_winv, pred0_winv, pred1_winv;
     int dilation[7];
     int feat_channels;
     const void *head_wd;        /* the head block's two de_location input channels as one 32-deep
                                    K step: (2,1,4,128,8) packing of W'[o][k], k = 9 ring taps of dx,
-                                   9 of dy, 14 zeros, with head_w's scale (dance_gather_head16w);
-                                   null: dance_snake_evolve16 uses dance_gather_head16 */
+                                   9 of dy, 14 zeros (dance_gather_head16w) */
+    float head_wd_winv;         /* head_wd's own inverse scale: the feature columns (head_w, whose
+                                   de_location columns are zero) and the de_location columns are
+                                   packed at separate powers of two */
 } dance_snake_net16;
 
 /* The 7 residual SnakeBlocks (res_* fields of the net) in one launch, v <= 256: state is the
  * (n, 8 slots) P16 block, slot 0 = head output (input), slots 1..7 receive the block outputs;
- * same results as 7 dance_conv16 calls (bit-identical up to 128 vertices; above, within 1e-5:
- * another MFMA shape, hence summation order), one kernel tail and launch gap instead of 7.
- * The ring runs ceil(v / 16) vertex tiles of 16 (at most one more): LDS images of 64, 96, 128, 160,
- * 192, 224 or 256 columns; above 128 vertices (and for 97..128 with at most DANCE_STACK_SMALL_N
- * contours) 8 waves per contour with the tiles split over two groups of waves, odd counts as k + (k - 1).
- * reference: _SnakeNet.forward snake_head.py:262-268. */
+ * same results as 7 dance_conv16 calls up to summation order (1e-5), one kernel tail and launch
+ * gap instead of 7.  The ring runs ceil(v / 16) vertex tiles of 16 (at most one more): LDS images
+ * of 64, 96, 128, 160, 192, 224 or 256 columns; above 128 vertices (and for 97..128 with few
+ * contours, policy) 8 waves per contour with the tiles split over two groups of waves, odd counts as
+ * k + (k - 1).  reference: _SnakeNet.forward snake_head.py:262-268. */
 int dance_res_stack16(const dance_snake_net16 *net_host, void *state, int64_t stride, int64_t slot,
-                      int n, int v, int mfma_terms, void *stream);
+                      int n, int v, int mfma_terms, const dance_policy *policy, void *stream);
 
-/* dance_gather_head16 followed by dance_res_stack16 in ONE launch (v <= 128): the head block's
- * output goes to slot 0 of `state` and straight into the LDS image the residual blocks work on.
- * Bit-identical to the two separate calls.  reference: evolve snake_head.py:1639-1652 +
- * _SnakeNet.forward :262-268. */
-int dance_head_stack16(const dance_snake_net16 *net_host, const float *feat, const float *att,
-                       const float *loc, const int32_t *image_idx, void *state, int64_t stride,
-                       int64_t slot, float *att_out, int n, int v, int b, int hf, int wf,
-                       int padding_mode, int deloc_type, int mfma_terms, void *stream);
-
-/* dance_snake_evolve in the fast precision mode (same workspace size, same stage events;
- * the fusion / row-constant / prediction[0] stages are one kernel).  net32 is unused (kept for
- * the signature; x_in now runs dance_xin_head16). */
-int dance_snake_evolve16(const dance_snake_net16 *net_host, const dance_snake_net *net32_host,
-                         const float *feat, const float *att, const float *loc,
-                         const int32_t *image_idx, const float *whs, const float *x_in, float *out,
-                         void *workspace, int64_t workspace_bytes, int n, int v, int b, int hf,
-                         int wf, int padding_mode, int deloc_type, int individual_scale, int use_att,
-                         int clip_first, float clip_x_max, float clip_y_max, int mfma_terms,
+/* dance_snake_evolve in the fast precision mode (same workspace size, same stage events):
+ * dance_gather_head16w -> dance_res_stack16 -> dance_fuse16w_raw(_split) -> dance_tail16.
+ * feat_absmax: the features' per-image max words (dance_nchw_to_nhwc / dance_gn_relu /
+ * dance_feature_absmax), or NULL = the head block's input is split unscaled. */
+int dance_snake_evolve16(const dance_snake_net16 *net_host, const float *feat, const float *att,
+                         const uint32_t *feat_absmax, const float *loc, const int32_t *image_idx,
+                         const float *whs, float *out, void *workspace, int64_t workspace_bytes,
+                         int n, int v, int b, int hf, int wf, int padding_mode, int deloc_type,
+                         int individual_scale, int use_att, int clip_first, float clip_x_max,
+                         float clip_y_max, int mfma_terms, const dance_policy *policy,
                          void **stage_events_host, void *stream);
 
 /* Dsnake's whole init stage in the fast precision mode: dance_init_head16 with the init snake's
@@ -609,8 +615,8 @@ int dance_snake_evolve16(const dance_snake_net16 *net_host, const dance_snake_ne
 int dance_snake_init16(const dance_snake_net16 *net_host, const dance_init_fuse16 *fuse_host,
                        const float *feat, const float *loc, const int32_t *image_idx, float *out,
                        void *workspace, int64_t workspace_bytes, int n, int v, int b, int hf, int wf,
-                       int padding_mode, int deloc_type, int mfma_terms, void **stage_events_host,
-                       void *stream);
+                       int padding_mode, int deloc_type, int mfma_terms, const uint32_t *feat_absmax,
+                       const dance_policy *policy, void **stage_events_host, void *stream);
 
 #ifdef __cplusplus
 }

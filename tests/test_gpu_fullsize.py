@@ -232,7 +232,12 @@ def test_config1_single_image_100x128_every_contour(device):
                        clip_max=(WF * 4 - 1, HF * 4 - 1))
         assert_coords_close(one, want[it], "config 1, iteration %d, all contours" % it)
         prev = want[it].to(device)
-    # the quirk at full size: contour 0 inside the image, contour 1 free to leave it
-    last = got[-1].cpu()
-    assert float(last[0, :, 0].min()) >= 0.0 and float(last[0, :, 1].min()) >= 0.0
-    assert float(want[-1][1, :, 0].max()) > WF * 4 - 1 and torch.equal(last[1] > WF * 4 - 1, want[-1][1] > WF * 4 - 1)
+    # the quirk at full size, after iteration 0: contour 0 clamped into the image (and onto its border),
+    # contour 1 free to leave it.  (Contour 0 then collapses onto y = 0 with these weights, so the
+    # reference's eps-free derange makes it NaN from iteration 1 on -- here too: coord_rel_err above
+    # demands the NaNs at identical places.)
+    first, w0 = got[0].cpu(), want[0]
+    assert float(first[0].min()) >= 0.0 and float(first[0, :, 0].max()) <= WF * 4 - 1 and bool((first[0] == 0).any())
+    out1 = (w0[1, :, 0] > WF * 4 - 1) | (w0[1, :, 1] > HF * 4 - 1)
+    assert bool(out1.any()) and torch.equal((first[1, :, 0] > WF * 4 - 1) | (first[1, :, 1] > HF * 4 - 1), out1)
+    assert bool(torch.isnan(want[2][0]).all()) and bool(torch.isfinite(want[2][1:]).all())

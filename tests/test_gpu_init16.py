@@ -133,4 +133,4 @@ def test_init_evolve_rejects_unsupported_shapes_and_accepts_empty(device):
     with torch.cuda.device(device), pytest.raises(RuntimeError):
         check(lib().dance_snake_init16(ctypes.byref(d.nets[0].struct16), ctypes.byref(head._fuse16), ptr(feat),
                                        ptr(rings), ptr(idx), ptr(out), ptr(ws), ws.numel(), 3, 128, 1, 16, 16,
-                                       ops.PAD_ZEROS, ops.DELOC["demin"], 3, None, current_stream()), "init16")
+                                       ops.PAD_ZEROS, ops.DELOC["demin"], 3, None, None, None, current_stream()), "init16")

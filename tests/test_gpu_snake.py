@@ -110,11 +110,12 @@ def test_pointwise_rowinit_maxv(device):
     assert float(out[:, 64:].abs().max()) == 0.0
 
 
-def _net_forward(sd, x, device, precision="fp16x3"):
-    """whole _SnakeNet through dance_snake_evolve's x_in path: returns raw offsets (N,V,2)."""
+def _net_forward(sd, x, device):
+    """whole _SnakeNet through dance_snake_evolve's x_in path (a precomputed input always runs the
+    exact-fp32 kernels): returns raw offsets (N,V,2)."""
     net = snake.SnakeNetWeights(sd, device)
     d = snake.ContourDeformer([net], padding="zeros", de_loc_type="demin", individual_scale=False,
-                              attention=False, precision=precision)
+                              attention=False)
     n, _, v = x.shape
     loc = torch.zeros((n, v, 2), device=device)
     feat = torch.zeros((1, 2, 2, 256), device=device)
@@ -122,14 +123,14 @@ def _net_forward(sd, x, device, precision="fp16x3"):
                     x_in=x.to(device).contiguous())
 
 
-@pytest.mark.parametrize("precision", ["fp16x3", "fp32"])
-def test_snake_net_golden(device, precision):
+def test_snake_net_golden(device):
+    """(the fast mode's whole net is held to the golden chains below, per iteration)"""
     g = golden("g4_snake_net")
     for tag in ("v128", "v196", "v40"):
         net = modules._SnakeNet(128, 258, (1, 1, 1, 2, 2, 4, 4))
         sd = {k: v.clone() for k, v in net.state_dict().items()}
         synthetic.fill_state_dict_(sd, int(g[tag + "_seed"]))
-        off = _net_forward(sd, g[tag + "_x"], device, precision)  # loc = 0 -> output = offsets
+        off = _net_forward(sd, g[tag + "_x"], device)             # loc = 0 -> output = offsets
         want = g[tag + "_y"].permute(0, 2, 1)
         assert rel_err(off, want, floor=float(want.abs().max())) < 1e-4, tag
 
@@ -276,41 +277,60 @@ def test_deterministic_and_chunked(device):
 
 
 @pytest.mark.parametrize("v", [16, 40, 64, 68, 80, 96, 100, 112, 128, 132, 144, 148, 160, 164, 176, 180, 192, 196, 208, 224, 228, 256])
-def test_res_stack_equals_seven_launches(device, v):
-    """dance_res_stack16 (7 residual blocks, activations resident in LDS) against 7 dance_conv16
-    launches through HBM, for both MFMA term counts: bit-identical up to 128 vertices."""
+def test_res_stack_vs_single_blocks_and_torch(device, v):
+    """dance_res_stack16 (7 residual blocks, activations resident in LDS, every slot at its own
+    activation scale) against 7 dance_conv16 launches through HBM (same products, another MFMA shape,
+    hence summation order) and against torch fp32 from the same weights, for both MFMA term counts."""
     import ctypes
-    from dance_amd._lib import check, current_stream, lib, ptr
+    from dance_amd._lib import PolicyStruct, check, current_stream, lib, ptr
+    from _fast_ref import res_block_ref, slot_scales, true_state, w32
     cfg, sd, _ = dance_state_dict(99, 128)
-    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer1."), device)
+    sub = snake.sub_state_dict(sd, "deformer1.")
+    net = snake.SnakeNetWeights(sub, device)
+    w = w32(sub, device)
     s16 = net.struct16
     slot = 256 * v
+    sc0 = float(slot_scales(net, device)[0])
     # 65..128 vertices: up to 256 contours run the 8-wave kernel, more the 4-wave one (5, 6, 7 or 8 vertex
     # tiles) -- cover both
     for n, terms in [(37, 3), (37, 1)] + ([(300, 3), (300, 1)] if 64 < v <= 128 else []):
         x = torch.randn((n, 128, v), generator=torch.Generator().manual_seed(v)) * 2
         a = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
-        a[:, 0] = ops.to_p16(x.to(device))[:, 0]
+        a[:, 0] = ops.to_p16((x * sc0).to(device))[:, 0]
         b = a.clone()
         with torch.cuda.device(device):
             st = current_stream()
-            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(a), a.stride(0), slot, n, v, terms, st), "stack")
+            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(a), a.stride(0), slot, n, v, terms, None, st), "stack")
             for i in range(7):
                 check(lib().dance_conv16(ptr(b[:, i]), b.stride(0), slot, s16.res_w[i], s16.res_bs[i],
                                          s16.res_winv[i], s16.res_scale[i], s16.res_shift[i], None, 1, 1, 0,
-                                         ptr(b[:, i + 1]), b.stride(0), slot, None, 0, n, v, 128, 128, 9,
-                                         s16.dilation[i], terms, st), "conv16")
-        if v <= 128:
-            assert torch.equal(a, b), (v, terms)
-        else:
-            # rings above 128 vertices: the stack runs 16x16x32 MFMAs, the per-block launches
-            # 32x32x16 ones -- same products, another summation order inside the matrix pipe
-            # (with one term per product the operands are plain fp16: a last-bit difference in
-            # one block flips roundings of the next block's inputs, 5e-4 each)
-            fa, fb = ops.from_p16(a), ops.from_p16(b)
-            rel = float((fa - fb).abs().max()) / float(fb.abs().max())
-            assert rel <= (1e-5 if terms == 3 else 5e-3), (v, terms, rel)
+                                         ptr(b[:, i + 1]), b.stride(0), slot, None, 0, s16.res_rmul[i], n, v, 128, 128,
+                                         9, s16.dilation[i], terms, st), "conv16")
+        fa, fb = true_state(net, a), true_state(net, b)
+        # (with one term per product the operands are plain fp16: a last-bit difference in one block
+        # flips roundings of the next block's inputs, 5e-4 each)
+        tol = 1e-5 if terms == 3 else 5e-3
+        rel = float((fa - fb).abs().max()) / float(fb.abs().max())
+        assert rel <= tol, (v, terms, rel)
         assert bool(torch.isfinite(a.float()).all()) and float(a[:, 7].float().abs().max()) > 0
+        want, cur = [fa[:, :128]], fa[:, :128]
+        for i in range(7):
+            cur = res_block_ref(w, i, cur, s16.dilation[i])
+            want.append(cur)
+        want = torch.cat(want, dim=1)
+        rel = float((fa - want).abs().max()) / float(want.abs().max())
+        assert rel <= (2e-5 if terms == 3 else 2e-2), (v, terms, rel)
+    if 64 < v <= 128:           # the 8-wave form for few contours against the 4-wave one: identical bits
+        x = torch.randn((37, 128, v), generator=torch.Generator().manual_seed(v + 1)) * 2
+        c = torch.zeros((37, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
+        c[:, 0] = ops.to_p16((x * sc0).to(device))[:, 0]
+        e = c.clone()
+        with torch.cuda.device(device):
+            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(c), c.stride(0), slot, 37, v, 3, None,
+                                          current_stream()), "stack")
+            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(e), e.stride(0), slot, 37, v, 3,
+                                          ctypes.byref(PolicyStruct(few_contour_forms=0)), current_stream()), "stack")
+        assert torch.equal(c.view(torch.int16), e.view(torch.int16))
 
 
 def test_deformation_replays_from_a_hip_graph(device):
@@ -349,48 +369,11 @@ def test_deformation_replays_from_a_hip_graph(device):
     assert torch.equal(out, want) and not torch.equal(out, eager)
 
 
-@pytest.mark.parametrize("v", [16, 40, 100, 128])
-def test_head_stack_equals_separate_launches(device, v):
-    """dance_head_stack16 (gather + head block + 7 residual blocks in one launch, the head's
-    output handed over in LDS) is bit-identical to dance_gather_head16 + dance_res_stack16."""
-    import ctypes
-    from dance_amd._lib import check, current_stream, lib, ptr
-    cfg, sd, _ = dance_state_dict(77, 128)
-    net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer2."), device)
-    s16 = net.struct16
-    b, hf, wf, n = 2, 40, 56, 29
-    feats = synthetic.make_features(b, 256, hf, wf, 5).to(device)
-    nhwc, att = ops.nchw_to_nhwc(feats, 1)
-    boxes = synthetic.make_boxes(n, hf * 4, wf * 4, v, r_min=6, r_max=50)
-    loc = synthetic.make_circle_contours(boxes, v).to(device)
-    loc[3] += 400.0                                             # leaves the image: reflection padding
-    idx = (torch.arange(n) % b).to(torch.int32).to(device)
-    slot = 256 * v
-    for terms in (3, 1):
-        a = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
-        bb = a.clone()
-        att_a = torch.zeros((n, v), device=device)
-        att_b = torch.zeros((n, v), device=device)
-        with torch.cuda.device(device):
-            st = current_stream()
-            check(lib().dance_head_stack16(ctypes.byref(s16), ptr(nhwc), ptr(att), ptr(loc), ptr(idx), ptr(a),
-                                           a.stride(0), slot, ptr(att_a), n, v, b, hf, wf, ops.PAD_REFLECTION,
-                                           ops.DELOC["derange"], terms, st), "head_stack16")
-            check(lib().dance_gather_head16(ptr(nhwc), ptr(att), ptr(loc), ptr(idx), s16.head_w, None, s16.head_bs,
-                                            s16.head_winv, s16.head_scale, s16.head_shift, ptr(bb), bb.stride(0),
-                                            ptr(att_b), n, v, b, hf, wf, 256, ops.PAD_REFLECTION,
-                                            ops.DELOC["derange"], terms, st), "gather_head16")
-            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(bb), bb.stride(0), slot, n, v, terms, st), "stack")
-        assert torch.equal(a, bb), (v, terms)
-        assert torch.equal(att_a, att_b)
-        assert bool(torch.isfinite(a.float()).all()) and float(a[:, 7].float().abs().max()) > 0
-
-
 @pytest.mark.parametrize("v", [64, 128, 132, 196, 224, 256])
 def test_conv16_pointwise_forms(device, v):
     """dance_conv16 as the k=1 Conv1d's of the snake net in the fast mode -- fusion + max over the
     ring, prediction[0] with a per-contour row constant, prediction[1] (64 outputs, fp32 out) --
-    against torch fp32; above 128 vertices these run the 8-wave k_conv16w."""
+    against torch fp32."""
     g = torch.Generator().manual_seed(v)
     n = 7
     x = torch.randn((n, 1024, v), generator=g)
