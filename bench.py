@@ -8,7 +8,10 @@
 process per GPU (as the reference's train_net.py:76-83 `launch(main, args.num_gpus, ...)` does):
 the parent never touches the GPU, runs `python -m torch.distributed.run` as a child process and
 exits with its status; rank 0's JSON line passes through.  Under an existing launcher
-(WORLD_SIZE set) `--gpus` must equal WORLD_SIZE.
+(WORLD_SIZE set) `--gpus` must equal WORLD_SIZE.  `--force-dist` takes the same route with ONE
+rank: launcher child, `init_process_group("nccl", device_id=...)`, the counts + padded
+`all_gather_into_tensor` of the exchange step and the barriers all run at world size 1 -- the
+whole multi-rank path on a single GPU (tests/test_gpu_dist1.py).
 
 Workloads
   cfg2 (default; the configuration the BASELINE metric is quoted on), weak scaling: per GPU,
@@ -97,6 +100,11 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=1,
                     help="deform the contours in this many parts on separate HIP streams (no per-stage "
                          "events then; measured -4 %% wall with 2)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-rank path whatever --gpus is: ranks started by the launcher child, RCCL "
+                         "process group, exchange-step collectives and barriers also at world size 1")
+    ap.add_argument("--dump-output", default=None,
+                    help="rank 0 saves its gathered output contours to this file (torch.save) -- for comparing runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-feat-prep", action="store_true", help="skip the untimed bottom_out measurement")
     ap.add_argument("--no-extras", action="store_true",
@@ -138,7 +146,8 @@ def dry_run_cpu(args, rank, world):
     of the HIP deformer (every vertex moves by (image + 1, 2 * image + 1)), at toy sizes."""
     from dance_amd.distributed import ImageShard, all_gather_contours, gather_shards
 
-    if world > 1:
+    grouped = world > 1 or args.force_dist
+    if grouped:
         dist.init_process_group("gloo")
     b, v = 8, 8
     per = [1 + (i * 5) % 4 for i in range(b)]                     # ragged instances per image
@@ -162,13 +171,14 @@ def dry_run_cpu(args, rank, world):
         want = torch.cat([stub(full + r, image_idx) for r in range(world)])
     ok = torch.equal(out, want)
     t = torch.tensor([float(ok)])
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(json.dumps({"dry_run": True, "metric": "DRY RUN on the CPU (gloo, stub deformer): not a measurement",
                           "n_gpus": world, "gpus_flag": args.gpus, "scaling": args.scaling,
-                          "contours": int(out.size(0)), "ok": bool(t.item() == 1.0)}))
-    if world > 1:
+                          "contours": int(out.size(0)), "ok": bool(t.item() == 1.0),
+                          "process_group": grouped}))
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0 if t.item() == 1.0 else 1
@@ -207,7 +217,7 @@ def cpu_baseline(reps):
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         launch_ranks(args, argv)                                 # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -216,7 +226,8 @@ def main():
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if args.dry_run_cpu:
         sys.exit(dry_run_cpu(args, rank, world))
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
@@ -225,7 +236,7 @@ def main():
 
     from dance_amd import config, modules, ops, snake, synthetic
     from dance_amd._lib import EVOLVE_EVENTS, STAGE_NAMES
-    from dance_amd.distributed import ImageShard, all_gather_contours, gather_shards
+    from dance_amd.distributed import CALLS, ImageShard, all_gather_contours, gather_shards
 
     per, v = args.per_image, args.vertices
     h, w = HF * 4, WF * 4
@@ -313,23 +324,27 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    calls0 = CALLS["all_gather_into_tensor"]
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = step(events[k] if events else None, layout_ev[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    timed_collectives = CALLS["all_gather_into_tensor"] - calls0
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (n_total, v, 2) and bool(torch.isfinite(out).all())
     mine = out[shard.index.to(dev)] if strong else out[rank * n:(rank + 1) * n]   # this rank's rows of the gathered set
+    if rank == 0 and args.dump_output:
+        torch.save(out.cpu(), args.dump_output)
     if rank == 0:
         # instrumented single-stream pass (every stage boundary) over the first chunk; with
         # --streams > 1 or a chunked batch it also supplies the three timed events
@@ -346,8 +361,9 @@ def main():
     # the headline, never as it: per-kernel event timing is only meaningful on one stream.
     two_streams = None
     # the untimed extras (stages either side of the path) run at the one-GPU weak workloads only
-    extras = rank == 0 and not strong and b <= 32 and not args.no_extras
-    if extras and world == 1 and args.streams == 1:
+    # (and never in a multi-rank run: the other ranks would sit in the final barrier meanwhile)
+    extras = rank == 0 and world == 1 and not strong and b <= 32 and not args.no_extras
+    if extras and args.streams == 1:
         def step2():
             f = deformer.prepare_features(feats) if pre is None else pre
             return deformer.deform(f, init, image_idx, sizes, whs, layout="nhwc", streams=2)[-1]
@@ -650,29 +666,20 @@ def main():
                       for k in range(args.steps) for it in range(ITERS)) / launches
         res7_ms = sum(events[k][it][1].elapsed_time(events[k][it][8])
                       for k in range(args.steps) for it in range(ITERS)) / launches
-        stacked = args.precision != "fp32" and os.environ.get("DANCE_RES_STACK", "1") != "0" and \
-            (v <= 128 or os.environ.get("DANCE_RES_STACK_WIDE", "1") != "0")
-        # DANCE_HEAD_STACK=1 (opt-in): gather + head block + the 7 residual blocks are ONE launch
-        # (k_head_stack16s); the events before the head and after the last residual block bracket it
-        head_stack = stacked and v <= 128 and os.environ.get("DANCE_HEAD_STACK", "0") != "0"
-        if head_stack:
-            head_ms = head_ms + res7_ms                         # the fused launch
-            macs_dom = (CH + 2) * 128 * 9 + 7 * MACS_RES_BLOCK
-            res_ms = head_ms
-            res_tflops = 2.0 * macs_dom * v * n_ev / (res_ms * 1e-3) / 1e12     # algorithmic
-        else:
-            res_ms = res7_ms / 7.0                              # per residual block
-            res_tflops = 2.0 * MACS_RES_BLOCK * v * n_ev / (res_ms * 1e-3) / 1e12  # algorithmic
+        stacked = args.precision != "fp32"                      # fast mode: the 7 blocks are one launch
+        res_ms = res7_ms / 7.0                                  # per residual block
+        res_tflops = 2.0 * MACS_RES_BLOCK * v * n_ev / (res_ms * 1e-3) / 1e12  # algorithmic
         gather_gbps = GATHER_BYTES_PER_VERTEX * v * n_ev / (head_ms * 1e-3) / 1e9
         layout_ms = (sum(a.elapsed_time(b_) for a, b_ in layout_ev) / args.steps) if pre is None else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         total_flops = 2.0 * MACS_PER_VERTEX * v * n_total * ITERS     # whole job
+        # dance_res_stack16's dispatch (csrc/snake16.hip): LDS image width in 32-column units, the
+        # 8-wave kernel above 128 vertices and for few contours (policy.few_contour_forms), an odd
+        # number of 16-wide vertex tiles as k + (k - 1)
         rt = 2 if v <= 64 else 4 if v <= 128 else 7 if v <= 224 else 8
-        if os.environ.get("DANCE_STACK_MID", "1") != "0":       # dance_res_stack16's image widths
-            rt = 3 if 64 < v <= 96 else 5 if 128 < v <= 160 else 6 if 160 < v <= 192 else rt
-        # dance_res_stack16's dispatch: 8-wave kernel above 128 vertices and for few long rings
-        stack_wide = v > 128 or (v > 96 and n_ev <= int(os.environ.get("DANCE_STACK_SMALL_N", "256")))
-        stack13 = 192 < v <= 208 and os.environ.get("DANCE_STACK_ODD_SPLIT", "1") != "0"   # 13 vertex tiles as 7 + 6
+        rt = 3 if 64 < v <= 96 else 5 if 128 < v <= 160 else 6 if 160 < v <= 192 else rt
+        stack_wide = v > 128 or (v > 64 and n_ev <= 256)
+        stack13 = stack_wide and v > 128 and (-(-v // 16)) % 2 == 1
         if args.precision in ("fp16x3", "fp16"):
             terms = 3 if args.precision == "fp16x3" else 1
             # every algorithmic product is three f16 MFMA products (A_lo*B_hi + A_hi*B_lo +
@@ -680,15 +687,9 @@ def main():
             # the f16 dense peak; `frac_executed` counts the three MFMAs each product costs (the pipe
             # utilisation); `frac_vs_f32_mfma_peak` is the same useful rate against the fp32-MFMA peak
             # that the reference's own fp32 arithmetic would be limited to
-            kname = ("k_head_stack16s<%d,%d> (gather + head SnakeBlock 258->128 + the 7 residual SnakeBlocks "
-                     "128->128, k=9, in one launch; %s f16 MFMA)" if head_stack else
-                     ("k_res_stack16w13" if stack13 else "k_res_stack16w" if stack_wide else "k_res_stack16s") +
-                     "<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; "
-                     "%s f16 MFMA 16x16x32)" if stacked else
-                     "k_conv16%s<%d,%d> (residual SnakeBlock 128->128, k=9, %s f16 MFMA; 7 launches "
-                     "between the two events, figures per launch)")
-            kname = kname % ((rt, terms, "split-half" if terms == 3 else "single-term") if stacked else
-                             ("s" if rt <= 4 else "", rt, terms, "split-half" if terms == 3 else "single-term"))
+            kname = (("k_res_stack16w13" if stack13 else "k_res_stack16w" if stack_wide else "k_res_stack16s") +
+                     "<%d,%d> (the 7 residual SnakeBlocks 128->128, k=9, in one launch; %s f16 MFMA 16x16x32)") % (
+                         4 if stack_wide and v <= 128 else rt, terms, "split-half" if terms == 3 else "single-term")
             roof = {"kernel": kname,
                     "bound": "mfma", "achieved": res_tflops, "peak": PEAK_F16_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": res_tflops / PEAK_F16_MFMA_TFLOPS, "traffic": None,
@@ -696,9 +697,8 @@ def main():
                     "achieved_executed": terms * res_tflops,
                     "frac_executed": terms * res_tflops / PEAK_F16_MFMA_TFLOPS,
                     "frac_vs_f32_mfma_peak": res_tflops / PEAK_F32_MFMA_TFLOPS,
-                    "avg_launch_ms": res_ms if head_stack else res7_ms if stacked else res_ms,
-                    "algorithmic_GFLOP_per_launch": (2.0 * macs_dom * v * n_ev / 1e9 if head_stack else
-                                                     2.0 * MACS_RES_BLOCK * v * n_ev * (7 if stacked else 1) / 1e9),
+                    "avg_launch_ms": res7_ms,
+                    "algorithmic_GFLOP_per_launch": 2.0 * MACS_RES_BLOCK * v * n_ev * 7 / 1e9,
                     "algorithmic_TFLOPs": res_tflops, "mfma_per_product": terms,
                     "contours_per_launch": n_ev,
                     "note": "achieved = algorithmic flops per launch / spacing of the two HIP events around the "
@@ -706,7 +706,7 @@ def main():
                             + ("recorded inside the timed steps" if single_chunk and args.streams == 1 else
                                "recorded in an instrumented pass over the first %d contours after the timed "
                                "region" % n_ev) + "; executed = %d f16 MFMAs per product" % terms}
-            if side_n and stacked and not head_stack:
+            if side_n:
                 # the timed launch shares the CUs with the side stream's small kernels (the peeled
                 # remainder's chain); the same launch with the GPU to itself, from the instrumented
                 # single-stream pass over the same n_ev contours
@@ -719,15 +719,16 @@ def main():
                                          "(instrumented pass after the timed region)"}
             if terms == 3:
                 roof["traffic"], roof["traffic_source"] = measured_traffic(
-                    "k_head_stack16s" if head_stack else ("k_res_stack16w" if stack_wide else "k_res_stack16s")
-                    if stacked else
-                    "k_conv16s" if rt <= 4 else "k_conv16<", n_ev)
+                    "k_res_stack16w" if stack_wide else "k_res_stack16s", n_ev)
             dtype = "f16x3/f32acc" if terms == 3 else "f16/f32acc (approximate)"
-            gkernel = ("k_head_stack16s<%d> (fused gather + head SnakeBlock + residual stack)" % rt if head_stack
+            halves = v > 128 or (v > 64 and n_ev <= 128)           # dance_gather_head16w's dispatch (csrc/head16.hip)
+            gkernel = ("k_gather_head16h (fused gather + head SnakeBlock, two half-ring workgroups per contour)" if halves
                        else "k_gather_head16w<%d,%d> (fused gather + head SnakeBlock, 16-wide vertex tiles)" % (
-                           2 if v <= 64 else 4 if v <= 128 else 7, -(-v // 16))
-                       if v <= 208 and os.environ.get("DANCE_HEAD_SHAPE", "16") == "16"
-                       else "k_gather_head16<%d> (fused gather + head SnakeBlock)" % rt)
+                           2 if v <= 64 else 4, -(-v // 16)))
+            # the head kernel's own MFMA work: 256 feature channels x 9 ring taps + the de_location channels as
+            # one 32-deep K step, every product as `terms` f16 MFMAs
+            head_alg = 2.0 * (CH + 2) * 128 * 9 * v * n_ev / (head_ms * 1e-3) / 1e12
+            head_exec = terms * 2.0 * (CH * 9 + 32) * 128 * v * n_ev / (head_ms * 1e-3) / 1e12
         else:
             roof = {"kernel": "k_circconv<%d> (residual SnakeBlock 128->128, k=9, f32 MFMA)" % rt,
                     "bound": "mfma", "achieved": res_tflops, "peak": PEAK_F32_MFMA_TFLOPS,
@@ -738,6 +739,7 @@ def main():
                     "contours_per_launch": n_ev}
             dtype = "f32"
             gkernel = "k_gather_head<%d> (fused gather + head SnakeBlock)" % rt
+            head_alg = head_exec = 2.0 * (CH + 2) * 128 * 9 * v * n_ev / (head_ms * 1e-3) / 1e12
         line = {
             "metric": "contours deformed/sec (%d vertices, all iters)" % v,
             "value": n_total * args.steps / elapsed,
@@ -765,11 +767,15 @@ def main():
             "gather": {"kernel": gkernel,
                        "algorithmic_GBps": gather_gbps, "frac_of_hbm_peak": gather_gbps / PEAK_HBM_GBPS,
                        "avg_launch_ms": head_ms,
+                       "algorithmic_mfma_TFLOPs": head_alg, "executed_mfma_TFLOPs": head_exec,
+                       "frac_algorithmic_mfma": head_alg / (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32"
+                                                            else PEAK_F16_MFMA_TFLOPS),
+                       "frac_executed_mfma": head_exec / (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32"
+                                                          else PEAK_F16_MFMA_TFLOPS),
                        "note": "the fused kernel is MFMA-bound (%d MFLOP per 526 KB gathered per "
-                               "contour-iteration), not HBM-bound" % (
-                                   2.0 * ((CH + 2) * 128 * 9 + (7 * MACS_RES_BLOCK if head_stack else 0)) * v / 1e6),
-                       "traffic": measured_traffic("k_head_stack16s" if head_stack else
-                                                   "k_gather_head16" if args.precision != "fp32" else "k_gather_head<", n_ev)[0],
+                               "contour-iteration), not HBM-bound: frac_executed_mfma prices it against the roofline "
+                               "that binds it" % (2.0 * (CH + 2) * 128 * 9 * v / 1e6),
+                       "traffic": measured_traffic("k_gather_head16" if args.precision != "fp32" else "k_gather_head<", n_ev)[0],
                        "standalone_traffic": measured_traffic("k_gather|", 4 * n_ev)[0] if v == 128 else None,
                        "traffic_note": "HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json; "
                                        "neighbouring vertices share taps in L2, so fewer bytes are fetched than the "
@@ -801,10 +807,17 @@ def main():
                                  "ms": sampling_ms, "contours_per_s": n / (sampling_ms * 1e-3),
                                  "note": "reference scope `contour_sampling`, outside the timed step"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        line["rccl"] = {"initialised": bool(dist_on and dist.is_initialized()),
+                        "backend": dist.get_backend() if dist_on else None, "world_size": world,
+                        "all_gather_into_tensor_calls_in_timed_steps": timed_collectives,
+                        "note": "exchange step: %s; none without a process group" % (
+                            "counts all-gather + padded contour all-gather per step" if strong else
+                            "one contour all-gather per step")}
+        if not args.no_cpu_baseline:
+            # rank 0 only, after the timed region, at every world size (the other ranks wait in the barrier below)
             line["cpu_baseline"] = cpu_baseline(args.cpu_reps)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -104,3 +104,15 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
 def test_bench_refuses_a_world_that_differs_from_gpus():
     r = _bench("--gpus", "4", "--dry-run-cpu", env={"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "--gpus 4" in r.stderr
+
+
+def test_force_dist_runs_the_group_at_world_one():
+    """--force-dist: one rank through the launcher child, a process group and the exchange-step
+    collectives at world size 1 (gloo here; tests/test_gpu_dist1.py runs the same with RCCL)."""
+    r = _bench("--gpus", "1", "--force-dist", "--workload", "cfg5", "--dry-run-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ok"] is True and line["process_group"] is True
+    r = _bench("--gpus", "1", "--workload", "cfg5", "--dry-run-cpu")
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ok"] is True and line["process_group"] is False
