@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -63,6 +63,7 @@ class PolicyStruct(ctypes.Structure):
 
 
 ABSMAX_WORDS = 8            # DANCE_ABSMAX_WORDS
+ABSMAX_OF_LAYOUT, ABSMAX_OF_GN_RELU, ABSMAX_OF_FEATURES = 0, 1, 2
 
 
 class InitFuse16Struct(ctypes.Structure):
@@ -92,7 +93,7 @@ SIGNATURES = {
     "dance_nhwc_to_p16img": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "dance_upsample2x_add": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_conv3x3_16": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_nms_sorted": (c_int, [P, c_int, c_float, P, P, P, P]),
     "dance_nms_sorted_plain": (c_int, [P, c_int, c_float, P, P, P, P]),
     "dance_nms_sorted_plain_static": (c_int, [P, c_int, c_float, P, P, P]),
@@ -113,8 +114,9 @@ SIGNATURES = {
     "dance_multisegment_matching": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_uniform_upsample": (c_int, [c_int, P, c_int, c_int, c_int, P, P, P, P]),
     "dance_octagon_upsample": (c_int, [P, c_int64, c_int64, P, P, c_int, c_float, c_float, c_int, c_int, P, P, P, P, P]),
-    "dance_nchw_to_nhwc": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "dance_feature_absmax": (c_int, [P, c_int, c_int64, P, P]),
+    "dance_nchw_to_nhwc": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "dance_feature_absmax": (c_int, [P, c_int, c_int64, P, P, P]),
+    "dance_absmax_partials": (c_int64, [c_int, c_int, c_int64]),
     "dance_gather_features": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_int, P]),
     "dance_circconv": (c_int, [P, c_int64, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int,

@@ -83,28 +83,51 @@ __device__ __forceinline__ float absmax_acc(float m, float x)
     return __builtin_bit_cast(float, a > b ? a : b);
 }
 
-// Publishes a workgroup's max |value| (a non-negative float's bit pattern orders like an unsigned)
-// into one of the image's DANCE_ABSMAX_WORDS partial-maximum words; `wm`: 16 words of LDS.  All
-// threads of the workgroup must call (it holds a barrier).  The max of a set is independent of the
-// order it is taken in: the words, and everything scaled by them, are deterministic.
-__device__ __forceinline__ void publish_absmax(float local_max, unsigned *wm, uint32_t *words, unsigned spread)
+// Per-image max |value| of a tensor a kernel produces, measured on the way out WITHOUT atomics: every
+// workgroup stores its own maximum (a non-negative float's bit pattern orders like an unsigned) into
+// its slot of a partials array, a second tiny kernel folds an image's partials into the
+// DANCE_ABSMAX_WORDS words the consumers read.  (Atomic maxima into a handful of words were tried
+// first: 60,800 workgroups of the layout pass on one 32-byte line per image cost +0.13 ms of 0.35,
+// and any load of that line queues behind the atomics.)  The max of a set does not depend on the
+// order it is taken in: deterministic.
+//   absmax_stage    every thread: wave-level max -> wm[wave] (16 words of LDS); then a barrier;
+//   absmax_partial  thread 0 after that barrier: merge, one plain store.
+__device__ __forceinline__ void absmax_stage(float local_max, unsigned *wm)
 {
     unsigned m = __builtin_bit_cast(unsigned, local_max) & 0x7fffffffu;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1)
         m = max(m, (unsigned)__shfl_xor((int)m, s, 64));
-    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0)
-        wm[wave] = m;
-    __syncthreads();
+        wm[threadIdx.x >> 6] = m;
+}
+
+__device__ __forceinline__ void absmax_partial(const unsigned *wm, uint32_t *slot)
+{
     if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        unsigned m = wm[0];
         for (int i = 1; i < nw; ++i)
             m = max(m, wm[i]);
-        uint32_t *w = words + (spread % DANCE_ABSMAX_WORDS);
-        // a word that already holds as much needs no atomic (a stale read only costs a redundant one)
-        if (m > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(w, m);
+        *slot = m;
     }
+}
+
+// grid: one workgroup of 256 per image; partial (b, per_image) -> words (b, DANCE_ABSMAX_WORDS)
+static __global__ __launch_bounds__(256) void k_absmax_reduce(const uint32_t *__restrict__ partial, long long per_image,
+                                                              uint32_t *__restrict__ words)
+{
+    const uint32_t *p = partial + (long long)blockIdx.x * per_image;
+    unsigned m = 0;
+    for (long long i = threadIdx.x; i < per_image; i += 256)
+        m = max(m, p[i]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1)
+        m = max(m, (unsigned)__shfl_xor((int)m, s, 64));
+    if ((threadIdx.x & 63) == 0)
+        words[blockIdx.x * DANCE_ABSMAX_WORDS + (threadIdx.x >> 6)] = m;
+    if (threadIdx.x >= 4 && threadIdx.x < DANCE_ABSMAX_WORDS)
+        words[blockIdx.x * DANCE_ABSMAX_WORDS + threadIdx.x] = 0u;
 }
 #endif
 
@@ -139,6 +162,14 @@ inline int zero_async(void *p, size_t bytes, hipStream_t stream, const char *fn)
     size_t blocks = (bytes / 16 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
     hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned char *)p, bytes);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail((int)e, fn, hipGetErrorString(e));
+}
+
+inline int absmax_reduce_async(const uint32_t *partial, long long per_image, uint32_t *words, int b, hipStream_t stream,
+                               const char *fn)
+{
+    hipLaunchKernelGGL(k_absmax_reduce, dim3(b), dim3(256), 0, stream, partial, per_image, words);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail((int)e, fn, hipGetErrorString(e));
 }

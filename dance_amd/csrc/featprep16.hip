@@ -315,7 +315,7 @@ struct GnArgs {
     float eps;
     _Float16 *out16;        // P16 image or null
     float *out_nhwc;        // (b, h, w, c) or null
-    uint32_t *absmax;       // with out_nhwc: (b, DANCE_ABSMAX_WORDS) max |output| per image, or null (p16.h)
+    uint32_t *absmax;       // with out_nhwc: per-workgroup partial maxima of |output| (common.h), or null
     int c, group_ch;
     long long hw;
 };
@@ -347,9 +347,11 @@ __global__ __launch_bounds__(256) void k_gn_relu(GnArgs a)
         const float x = (v[i] - mu) * rstd * ga[i] + be[i];
         r[i] = x > 0.0f ? x : (x != x ? x : 0.0f);
     }
-    if (a.absmax != nullptr)                     // (uniform; holds a barrier)
-        dance::publish_absmax(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(0.0f, r[0]), r[1]), r[2]), r[3]),
-                              wm, a.absmax + b * DANCE_ABSMAX_WORDS, blockIdx.x + 5 * blockIdx.y);
+    if (a.absmax != nullptr) {                   // (uniform; holds a barrier) a.absmax: the partials (b, gridDim.y * gridDim.x)
+        dance::absmax_stage(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(0.0f, r[0]), r[1]), r[2]), r[3]), wm);
+        __syncthreads();
+        dance::absmax_partial(wm, a.absmax + ((long long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    }
     if (!live)
         return;
     if (a.out_nhwc) {
@@ -448,7 +450,7 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
 
 extern "C" int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamma,
                              const float *beta, float eps, int groups, void *out16, float *out_nhwc,
-                             uint32_t *absmax, int b, int c, int h, int w, void *stream)
+                             uint32_t *absmax, uint32_t *absmax_partial, int b, int c, int h, int w, void *stream)
 {
     DANCE_REQUIRE(b >= 0 && c >= 16 && c % 16 == 0 && h >= 1 && w >= 1);
     DANCE_REQUIRE(groups >= 1 && c % groups == 0 && (c / groups) % 4 == 0);
@@ -460,12 +462,13 @@ extern "C" int dance_gn_relu(const float *y_blocked, const double *stats, const 
     a.y = y_blocked; a.stats = stats; a.gamma = gamma; a.beta = beta; a.eps = eps;
     a.out16 = (_Float16 *)out16; a.out_nhwc = out_nhwc; a.c = c; a.group_ch = c / groups;
     a.hw = (long long)h * w;
-    a.absmax = out_nhwc ? absmax : nullptr;
-    if (a.absmax != nullptr) {
-        if (int rc = dance::zero_async(absmax, sizeof(uint32_t) * DANCE_ABSMAX_WORDS * (size_t)b, (hipStream_t)stream, __func__))
-            return rc;
-    }
-    hipLaunchKernelGGL(k_gn_relu, dim3((unsigned)((a.hw * 4 + 255) / 256), c / 16, b), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    DANCE_REQUIRE(absmax == nullptr || absmax_partial != nullptr);
+    a.absmax = out_nhwc && absmax ? absmax_partial : nullptr;
+    const dim3 grid((unsigned)((a.hw * 4 + 255) / 256), c / 16, b);
+    hipLaunchKernelGGL(k_gn_relu, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (int rc = launch_check(__func__))
+        return rc;
+    if (a.absmax != nullptr)
+        return dance::absmax_reduce_async(absmax_partial, (long long)grid.x * grid.y, absmax, b, (hipStream_t)stream, __func__);
     return launch_check(__func__);
 }

@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ 
             amax = dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(dance::absmax_acc(amax, v.x), v.y), v.z), v.w);
         }
     }
-    if (absmax != nullptr)                      // per-image max |feature| for the head block's input scale (p16.h);
-        dance::publish_absmax(amax, wm, absmax + ib * DANCE_ABSMAX_WORDS, blockIdx.x + 3 * blockIdx.y);   // holds a barrier
+    // per-image max |feature| for the head block's input scale (p16.h): staged in front of the tile's
+    // barrier, the workgroup's partial stored by one thread after the write phase
+    if (absmax != nullptr)
+        dance::absmax_stage(amax, wm);
     __syncthreads();
     {   // write: rows = pixels, 16 lanes x float4 along channels
         const int q = t & 15, r = t >> 4;
@@ -92,12 +94,14 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ 
             }
         }
     }
+    if (absmax != nullptr)                      // absmax: the partials (b, gridDim.y * gridDim.x)
+        dance::absmax_partial(wm, absmax + (ib * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // max |x| over each image of an NHWC feature tensor that did not come through dance_nchw_to_nhwc
 // or dance_gn_relu (which measure it on the way): one more read of the features
 __global__ __launch_bounds__(256) void k_feature_absmax(const float *__restrict__ feat, long long per_image,
-                                                        uint32_t *absmax)
+                                                        uint32_t *partial)
 {
     __shared__ unsigned wm[16];
     const long long ib = blockIdx.y;
@@ -111,26 +115,48 @@ __global__ __launch_bounds__(256) void k_feature_absmax(const float *__restrict_
     if (blockIdx.x == 0)
         for (long long i = (n4 << 2) + threadIdx.x; i < per_image; i += 256)
             amax = dance::absmax_acc(amax, f[i]);
-    dance::publish_absmax(amax, wm, absmax + ib * DANCE_ABSMAX_WORDS, blockIdx.x);
+    dance::absmax_stage(amax, wm);
+    __syncthreads();
+    dance::absmax_partial(wm, partial + ib * gridDim.x + blockIdx.x);
 }
 
-extern "C" int dance_feature_absmax(const float *feat, int b, int64_t per_image, uint32_t *absmax, void *stream)
+namespace {
+int feature_absmax_blocks(long long per_image)
+{
+    const long long blocks = (per_image / 4 + 255) / 256;
+    return (int)(blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks));
+}
+}  // namespace
+
+extern "C" int64_t dance_absmax_partials(int producer, int c, int64_t hw)
+{
+    if (c < 1 || hw < 1)
+        return 0;
+    switch (producer) {
+    case DANCE_ABSMAX_OF_LAYOUT: return (int64_t)dance::ceil_div((long long)hw, (long long)TP) * dance::ceil_div(c, TP);
+    case DANCE_ABSMAX_OF_GN_RELU: return (int64_t)((hw * 4 + 255) / 256) * (c / 16);
+    case DANCE_ABSMAX_OF_FEATURES: return feature_absmax_blocks((long long)c * hw);
+    default: return 0;
+    }
+}
+
+extern "C" int dance_feature_absmax(const float *feat, int b, int64_t per_image, uint32_t *absmax,
+                                    uint32_t *absmax_partial, void *stream)
 {
     DANCE_REQUIRE(b >= 0 && b <= 65535 && per_image >= 1);
     if (b == 0)
         return 0;
-    DANCE_REQUIRE(feat && absmax && ((uintptr_t)feat & 15) == 0 && (per_image % 4 == 0 || b == 1));
-    if (int rc = dance::zero_async(absmax, sizeof(uint32_t) * DANCE_ABSMAX_WORDS * (size_t)b, (hipStream_t)stream, __func__))
-        return rc;
-    const long long blocks = (per_image / 4 + 255) / 256;
-    const int gx = (int)(blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks));
+    DANCE_REQUIRE(feat && absmax && absmax_partial && ((uintptr_t)feat & 15) == 0 && (per_image % 4 == 0 || b == 1));
+    const int gx = feature_absmax_blocks(per_image);
     hipLaunchKernelGGL(k_feature_absmax, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, feat, (long long)per_image,
-                       absmax);
-    return launch_check(__func__);
+                       absmax_partial);
+    if (int rc = launch_check(__func__))
+        return rc;
+    return dance::absmax_reduce_async(absmax_partial, gx, absmax, b, (hipStream_t)stream, __func__);
 }
 
-extern "C" int dance_nchw_to_nhwc(const float *src, float *feat, float *att, uint32_t *absmax, int b, int c_total,
-                                  int att_channels, int hw, void *stream)
+extern "C" int dance_nchw_to_nhwc(const float *src, float *feat, float *att, uint32_t *absmax,
+                                  uint32_t *absmax_partial, int b, int c_total, int att_channels, int hw, void *stream)
 {
     DANCE_REQUIRE(b >= 0 && hw > 0 && (att_channels == 0 || att_channels == 1));
     DANCE_REQUIRE(c_total > att_channels);
@@ -138,15 +164,16 @@ extern "C" int dance_nchw_to_nhwc(const float *src, float *feat, float *att, uin
         return 0;
     DANCE_REQUIRE(src && feat && (att_channels == 0 || att));
     DANCE_REQUIRE(b <= 65535);
+    DANCE_REQUIRE(absmax == nullptr || absmax_partial != nullptr);
     const int c = c_total - att_channels;
     dim3 grid(dance::ceil_div(hw, TP), dance::ceil_div(c, TP), b);
-    if (absmax != nullptr) {
-        if (int rc = dance::zero_async(absmax, sizeof(uint32_t) * DANCE_ABSMAX_WORDS * (size_t)b, (hipStream_t)stream, __func__))
-            return rc;
-    }
     hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)stream, src, feat, att,
-                       c_total, att_channels, hw, absmax);
-    return launch_check(__func__);
+                       c_total, att_channels, hw, absmax ? absmax_partial : nullptr);
+    if (int rc = launch_check(__func__))
+        return rc;
+    if (absmax != nullptr)
+        return dance::absmax_reduce_async(absmax_partial, (long long)grid.x * grid.y, absmax, b, (hipStream_t)stream, __func__);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------

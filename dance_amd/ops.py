@@ -9,7 +9,8 @@ import os
 
 import torch
 
-from ._lib import ABSMAX_WORDS, check, current_stream, lib, ptr
+from ._lib import (ABSMAX_OF_FEATURES, ABSMAX_OF_GN_RELU, ABSMAX_OF_LAYOUT, ABSMAX_WORDS, check, current_stream,
+                   lib, ptr)
 
 POLY_RAW, POLY_BOX, POLY_QUAD, POLY_OCTAGON = 0, 1, 2, 3
 PAD_ZEROS, PAD_REFLECTION = 0, 1
@@ -219,10 +220,17 @@ def feature_absmax(feat_nhwc):
     b = feat_nhwc.size(0)
     words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=feat_nhwc.device)
     if b:
+        per_image = feat_nhwc[0].numel()
+        partial = _absmax_partial(ABSMAX_OF_FEATURES, b, 1, per_image, feat_nhwc.device)
         with torch.cuda.device(feat_nhwc.device):
-            check(lib().dance_feature_absmax(ptr(feat_nhwc), b, feat_nhwc[0].numel(), ptr(words), current_stream()),
+            check(lib().dance_feature_absmax(ptr(feat_nhwc), b, per_image, ptr(words), ptr(partial), current_stream()),
                   "feature_absmax")
     return words
+
+
+def _absmax_partial(producer, b, c, hw, device):
+    """scratch for a producer's per-workgroup maxima (include/dance_hip.h dance_absmax_partials)"""
+    return torch.empty((b, max(1, int(lib().dance_absmax_partials(producer, c, hw)))), dtype=torch.int32, device=device)
 
 
 def nchw_to_nhwc(features, att_channels):
@@ -235,9 +243,10 @@ def nchw_to_nhwc(features, att_channels):
     feat = torch.empty((b, hf, wf, c), dtype=torch.float32, device=features.device)
     att = torch.empty((b, hf, wf), dtype=torch.float32, device=features.device) if att_channels else None
     words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=features.device)
+    partial = _absmax_partial(ABSMAX_OF_LAYOUT, b, c, hf * wf, features.device)
     with torch.cuda.device(features.device):
-        check(lib().dance_nchw_to_nhwc(ptr(features), ptr(feat), ptr(att), ptr(words), b, ct, att_channels,
-                                       hf * wf, current_stream()), "nchw_to_nhwc")
+        check(lib().dance_nchw_to_nhwc(ptr(features), ptr(feat), ptr(att), ptr(words), ptr(partial), b, ct,
+                                       att_channels, hf * wf, current_stream()), "nchw_to_nhwc")
     setattr(feat, ABSMAX_ATTR, words)
     return feat, att
 
@@ -421,6 +430,7 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
     stats = torch.empty((b, groups, 2), dtype=torch.float64, device=dev)
     out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
     words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=dev)
+    partial = _absmax_partial(ABSMAX_OF_GN_RELU, b, c, h * w, dev)
     with torch.cuda.device(dev):
         st = current_stream()
         to_p16 = lib().dance_nhwc_to_p16img if nhwc_in else lib().dance_nchw_to_p16img
@@ -433,7 +443,7 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
             last = i + 1 == len(layers)
             check(lib().dance_gn_relu(ptr(yb), ptr(stats), ptr(gamma), ptr(beta), eps, groups,
                                       None if last else ptr(x16), ptr(out) if last else None,
-                                      ptr(words) if last else None, b, c, h, w, st),
+                                      ptr(words) if last else None, ptr(partial) if last else None, b, c, h, w, st),
                   "gn_relu")
     setattr(out, ABSMAX_ATTR, words)
     return out

@@ -157,10 +157,12 @@ int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_scale, float 
 /* dance_gn_relu: GroupNorm(groups, eps) * gamma + beta, then ReLU, of y_blocked using stats;
  *   exactly one of out16 (P16 image, the next layer's input) / out_nhwc ((b, h, w, c) fp32,
  *   what the gather kernels read) is non-null.  absmax (with out_nhwc; may be NULL): the
- *   per-image max |output| words of dance_nchw_to_nhwc, measured on the way out. */
+ *   per-image max |output| words of dance_nchw_to_nhwc, measured on the way out; absmax_partial
+ *   (b, dance_absmax_partials(DANCE_ABSMAX_OF_GN_RELU, c, h * w)) scratch, required with absmax. */
 int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamma,
                   const float *beta, float eps, int groups, void *out16, float *out_nhwc,
-                  uint32_t *absmax, int b, int c, int h, int w, void *stream);
+                  uint32_t *absmax, uint32_t *absmax_partial, int b, int c, int h, int w,
+                  void *stream);
 
 /* ------------------------------------ attention-map producer ------ */
 /* reference: EdgeSnakeFPNHead.attender, core/modeling/edge_snake/edge_det.py:66-100, applied
@@ -320,13 +322,22 @@ int dance_octagon_upsample(const float *ext_points, int64_t poly_stride, int64_t
  * att_channels == 1, channel 0 -> att (b, hw).  Replaces the split at
  * snake_head.py:1812-1814 / 1949-1951 plus the layout change the gather wants.
  * absmax (b, DANCE_ABSMAX_WORDS) u32 or NULL: per image, partial maxima of |feature| as float bit
- * patterns (zeroed here on the stream, then raised by atomic max -- order-independent, hence
- * deterministic); the fast mode's head block scales its input by them (dance_snake_evolve16). */
+ * patterns (a non-negative float orders like an unsigned; a NaN is above everything); the fast
+ * mode's head block scales its input by their maximum (dance_snake_evolve16).  Measured without
+ * atomics: every workgroup stores its own maximum into absmax_partial (b, dance_absmax_partials(
+ * DANCE_ABSMAX_OF_LAYOUT, c, hw)) u32 scratch (required with absmax), a second small launch folds
+ * them -- order-independent, hence deterministic. */
 #define DANCE_ABSMAX_WORDS 8
-int dance_nchw_to_nhwc(const float *src, float *feat, float *att, uint32_t *absmax, int b,
-                       int c_total, int att_channels, int hw, void *stream);
-/* The same words for an NHWC feature tensor that arrives from elsewhere: feat (b, per_image floats). */
-int dance_feature_absmax(const float *feat, int b, int64_t per_image, uint32_t *absmax, void *stream);
+enum { DANCE_ABSMAX_OF_LAYOUT = 0, DANCE_ABSMAX_OF_GN_RELU = 1, DANCE_ABSMAX_OF_FEATURES = 2 };
+/* scratch words PER IMAGE the producer needs for an image of c channels x hw pixels */
+int64_t dance_absmax_partials(int producer, int c, int64_t hw);
+int dance_nchw_to_nhwc(const float *src, float *feat, float *att, uint32_t *absmax,
+                       uint32_t *absmax_partial, int b, int c_total, int att_channels, int hw,
+                       void *stream);
+/* The same words for an NHWC feature tensor that arrives from elsewhere: feat (b, per_image floats);
+ * absmax_partial (b, dance_absmax_partials(DANCE_ABSMAX_OF_FEATURES, 1, per_image)). */
+int dance_feature_absmax(const float *feat, int b, int64_t per_image, uint32_t *absmax,
+                         uint32_t *absmax_partial, void *stream);
 
 /* ------------------------------------------------------------ gather (a1-a3) ------- */
 enum { DANCE_PAD_ZEROS = 0, DANCE_PAD_REFLECTION = 1 };

@@ -48,6 +48,9 @@ def test_bottom_out_shapes_vs_oracle(device, shape):
         want = snake_ref.bottom_out(sub, feats[:, 1:]).permute(0, 2, 3, 1)
         got = ops.bottom_out16(feats.to(device), 1, _layers(sd, device, n))
         assert rel_err(got, want) < 1e-4, (shape, n)
+        # the output carries its per-image max |value| words (the deformer's input scale), measured on the way out
+        words = ops.absmax_of(got)
+        assert torch.equal(words.view(torch.float32).max(1)[0], got.abs().flatten(1).max(1)[0])
         # the same tensor in channels_last memory is read in place (dance_nhwc_to_p16img):
         # 257 channels with the attention plane skipped (scalar loads), 256 (16-byte loads)
         cl = feats.to(device).contiguous(memory_format=torch.channels_last)

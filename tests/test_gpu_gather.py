@@ -76,3 +76,36 @@ def test_gather_single_point_and_empty(device):
     assert rel_err(x, snake_ref.get_locations_feature(feats, loc, idx, "zeros")) < 1e-5
     x, _ = ops.gather_features(nhwc, None, loc[:0].to(device), idx[:0].to(device), ops.PAD_ZEROS, "demin")
     assert x.shape == (0, 10, 1)
+
+
+@pytest.mark.parametrize("shape", [(3, 257, 40, 56), (2, 65, 7, 9), (1, 5, 3, 5), (2, 256, 25, 38)])
+def test_absmax_words(device, shape):
+    """the per-image max |feature| words the fast mode scales the head block's input by (csrc/p16.h):
+    from the layout pass and from dance_feature_absmax, against torch; order-independent, hence
+    bit-reproducible; a NaN wins; an all-zero image gives zeros"""
+    from dance_amd._lib import ABSMAX_WORDS
+    b, ct, hf, wf = shape
+    att = 1 if ct % 2 else 0
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(ct)) * 3
+    x[0, att:] *= 1e-6 if b > 1 else 1.0
+    if b > 1:
+        x[1, att:] = 0
+        x[1, att + 1, 1, 2] = -7.5e3
+    xd = x.to(device)
+    nhwc, _ = ops.nchw_to_nhwc(xd, att)
+    want = xd[:, att:].abs().flatten(1).max(1)[0]
+    for words in (ops.absmax_of(nhwc), ops.feature_absmax(nhwc.clone())):
+        assert words.shape == (b, ABSMAX_WORDS) and words.dtype == torch.int32
+        got = words.view(torch.float32).max(1)[0]
+        assert torch.equal(got, want)
+    again, _ = ops.nchw_to_nhwc(xd, att)
+    assert torch.equal(ops.absmax_of(again).view(torch.float32).max(1)[0], want)
+    # a NaN anywhere in an image: its words say so (bit pattern above every finite value)
+    xd[0, att, 0, 0] = float("nan")
+    nhwc, _ = ops.nchw_to_nhwc(xd, att)
+    for words in (ops.absmax_of(nhwc), ops.feature_absmax(nhwc.clone())):
+        assert int((words[0] & 0x7fffffff).max()) > 0x7f800000
+        if b > 1:
+            assert torch.equal(words[1:].view(torch.float32).max(1)[0], want[1:])
+    z, _ = ops.nchw_to_nhwc(torch.zeros(shape, device=device), att)
+    assert int(ops.absmax_of(z).abs().max()) == 0
