@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -92,7 +92,9 @@ SIGNATURES = {
     "dance_nchw_to_p16img": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "dance_nhwc_to_p16img": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P]),
     "dance_upsample2x_add": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
-    "dance_conv3x3_16": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_conv3x3_16": (c_int, [P, P, c_float, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_conv1x1_nhwc": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "dance_conv3x3_16_partial_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "dance_gn_relu": (c_int, [P, P, P, P, c_float, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "dance_nms_sorted": (c_int, [P, c_int, c_float, P, P, P, P]),
     "dance_nms_sorted_plain": (c_int, [P, c_int, c_float, P, P, P, P]),

@@ -12,7 +12,8 @@
 //                 packing), raw output (B,32,H,W) + group sums;
 //   k_att_out     per 32x16 tile: GN2 -> ReLU of the raw output with halo into LDS, conv3 + bias ->
 //                 sigmoid -> the attention plane the gather kernels read.
-// Group sums are fp32 per thread -> wave shuffle -> workgroup (LDS) -> one fp64 atomic per value.
+// Group sums are fp32 per thread -> wave shuffle -> workgroup (LDS) -> one partial per workgroup and value,
+// folded in fp64 in a fixed order by k_sum_rows (common.h): no atomics, two forwards give identical bits.
 #include "common.h"
 
 using dance::launch_check;
@@ -51,9 +52,9 @@ struct GroupSums {
                 s2[g] = fmaf(v, v, s2[g]);
             }
     }
-    // lanes -> wave (shuffles) -> workgroup (LDS, red: 4 x 8 floats) -> ONE fp64 atomic per value
-    // and workgroup: thousands of same-address atomics from every wave serialise in the L2
-    __device__ __forceinline__ void flush(double *st, float *red, int t)
+    // lanes -> wave (shuffles) -> workgroup (LDS, red: 4 x 8 floats) -> the workgroup's 8 partials
+    // (part: this workgroup's slot of 8 floats)
+    __device__ __forceinline__ void flush(float *part, float *red, int t)
     {
         const int lane = t & 63, wave = t >> 6;
 #pragma unroll
@@ -66,7 +67,7 @@ struct GroupSums {
         }
         __syncthreads();
         if (t < 8)
-            atomicAdd(st + t, (double)red[t] + (double)red[8 + t] + (double)red[16 + t] + (double)red[24 + t]);
+            part[t] = (red[t] + red[8 + t]) + (red[16 + t] + red[24 + t]);
     }
 };
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ float px(const float *x, int h, int w, int yy, int xx
 constexpr int AT_PPT = 8;                                       // pixels per thread in k_att_stats1
 
 __global__ __launch_bounds__(256) void k_att_stats1(const float *__restrict__ x, const float *__restrict__ w1,
-                                                    double *__restrict__ stats1, int h, int w)
+                                                    float *__restrict__ part1, int h, int w)
 {
     __shared__ float red[32];
     const int b = blockIdx.y;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void k_att_stats1(const float *__restrict__ x,
         }
         gs.add(y);
     }
-    gs.flush(stats1 + (long long)b * AT_G * 2, red, threadIdx.x);
+    gs.flush(part1 + ((long long)b * gridDim.x + blockIdx.x) * 8, red, threadIdx.x);
 }
 
 // conv2 tile: 32 x 16 pixels, two pixels (rows ty and ty + 8) per thread so that every scalar
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, 
                                                    const float *__restrict__ g1, const float *__restrict__ b1,
                                                    const double *__restrict__ stats1,
                                                    const float *__restrict__ w2p, float *__restrict__ y2,
-                                                   double *__restrict__ stats2, float eps, int h, int w)
+                                                   float *__restrict__ part2, float eps, int h, int w)
 {
     __shared__ float xt[AT_XY2][AT_XX];
     __shared__ float act[AT_CH][AT_HY2][AT_HX];
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void k_att_conv2(const float *__restrict__ x, 
             gs.add(acc[p]);
         }
     }
-    gs.flush(stats2 + (long long)b * AT_G * 2, red, t);
+    gs.flush(part2 + (((long long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8, red, t);
 }
 
 __global__ __launch_bounds__(256) void k_att_out(const float *__restrict__ y2, const float *__restrict__ g2,
@@ -273,11 +274,35 @@ __global__ __launch_bounds__(256) void k_att_out(const float *__restrict__ y2, c
 
 }  // namespace
 
+namespace {
+struct AttWorkspace {
+    double *stats1, *stats2;
+    float *y2, *part1, *part2;
+    long long wg1, tiles2;
+    int64_t bytes;
+};
+
+AttWorkspace att_carve(void *base, int b, int h, int w)
+{
+    AttWorkspace a;
+    a.wg1 = dance::ceil_div(h * w, 256 * AT_PPT);
+    a.tiles2 = (long long)dance::ceil_div(w, AT_TX) * dance::ceil_div(h, AT_TY2);
+    char *p = (char *)base;
+    a.stats1 = (double *)p;
+    a.stats2 = a.stats1 + (long long)b * AT_G * 2;
+    a.y2 = (float *)(a.stats2 + (long long)b * AT_G * 2);
+    a.part1 = a.y2 + (long long)b * AT_C * h * w;
+    a.part2 = a.part1 + (long long)b * a.wg1 * 8;
+    a.bytes = (int64_t)((char *)(a.part2 + (long long)b * a.tiles2 * 8) - p);
+    return a;
+}
+}  // namespace
+
 extern "C" int64_t dance_attender_workspace_bytes(int b, int h, int w)
 {
     if (b <= 0 || h <= 0 || w <= 0)
         return 0;
-    return (int64_t)b * AT_C * h * w * 4 + (int64_t)2 * b * AT_G * 2 * 8;
+    return att_carve(nullptr, b, h, w).bytes;
 }
 
 extern "C" int dance_attender(const float *x, const float *w1, const float *gn1_w, const float *gn1_b,
@@ -292,15 +317,15 @@ extern "C" int dance_attender(const float *x, const float *w1, const float *gn1_
     DANCE_REQUIRE(x && w1 && gn1_w && gn1_b && w2_packed && gn2_w && gn2_b && w3 && b3 && att && workspace);
     DANCE_REQUIRE(workspace_bytes >= dance_attender_workspace_bytes(b, h, w));
     hipStream_t s = (hipStream_t)stream;
-    double *stats1 = reinterpret_cast<double *>(workspace);
-    double *stats2 = stats1 + (long long)b * AT_G * 2;
-    float *y2 = reinterpret_cast<float *>(stats2 + (long long)b * AT_G * 2);
-    if (int rc = dance::zero_async(stats1, (size_t)2 * b * AT_G * 2 * 8, s, __func__))
+    const AttWorkspace ws = att_carve(workspace, b, h, w);
+    hipLaunchKernelGGL(k_att_stats1, dim3((unsigned)ws.wg1, b), dim3(256), 0, s, x, w1, ws.part1, h, w);
+    if (int rc = dance::sum_rows_async<8>(ws.part1, b, ws.wg1, ws.stats1, s, __func__))
         return rc;
-    hipLaunchKernelGGL(k_att_stats1, dim3(dance::ceil_div(h * w, 256 * AT_PPT), b), dim3(256), 0, s, x, w1, stats1, h, w);
     const dim3 tiles2(dance::ceil_div(w, AT_TX), dance::ceil_div(h, AT_TY2), b);
-    hipLaunchKernelGGL(k_att_conv2, tiles2, dim3(256), 0, s, x, w1, gn1_w, gn1_b, stats1, w2_packed, y2, stats2, eps,
-                       h, w);
-    hipLaunchKernelGGL(k_att_out, tiles2, dim3(256), 0, s, y2, gn2_w, gn2_b, stats2, w3, b3, att, eps, h, w);
+    hipLaunchKernelGGL(k_att_conv2, tiles2, dim3(256), 0, s, x, w1, gn1_w, gn1_b, ws.stats1, w2_packed, ws.y2, ws.part2,
+                       eps, h, w);
+    if (int rc = dance::sum_rows_async<8>(ws.part2, b, ws.tiles2, ws.stats2, s, __func__))
+        return rc;
+    hipLaunchKernelGGL(k_att_out, tiles2, dim3(256), 0, s, ws.y2, gn2_w, gn2_b, ws.stats2, w3, b3, att, eps, h, w);
     return launch_check(__func__);
 }

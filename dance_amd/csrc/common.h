@@ -166,6 +166,48 @@ inline int zero_async(void *p, size_t bytes, hipStream_t stream, const char *fn)
     return e == hipSuccess ? 0 : fail((int)e, fn, hipGetErrorString(e));
 }
 
+// Fixed-order sums for statistics that used to be fp64 atomics (run-to-run different in the last
+// bits): every producer workgroup stores its fp32 partial sums, this kernel adds a row's `count`
+// items of `NV` values each in fp64 -- thread t takes items t, t + 256, ... in order, then a fixed
+// tree over the 256 threads.  partial (rows, count, NV) f32 -> out (rows, NV) f64.  grid: rows.
+template <int NV>
+static __global__ __launch_bounds__(256) void k_sum_rows(const float *__restrict__ partial, long long count,
+                                                         double *__restrict__ out)
+{
+    __shared__ double red[256 * NV];
+    const float *p = partial + (long long)blockIdx.x * count * NV;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        acc[v] = 0.0;
+    for (long long i = threadIdx.x; i < count; i += 256)
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            acc[v] += (double)p[i * NV + v];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        red[threadIdx.x * NV + v] = acc[v];
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                red[threadIdx.x * NV + v] += red[(threadIdx.x + s) * NV + v];
+        __syncthreads();
+    }
+    if (threadIdx.x < NV)
+        out[(long long)blockIdx.x * NV + threadIdx.x] = red[threadIdx.x];
+}
+
+template <int NV>
+inline int sum_rows_async(const float *partial, long long rows, long long count, double *out, hipStream_t stream,
+                          const char *fn)
+{
+    hipLaunchKernelGGL(k_sum_rows<NV>, dim3((unsigned)rows), dim3(256), 0, stream, partial, count, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail((int)e, fn, hipGetErrorString(e));
+}
+
 inline int absmax_reduce_async(const uint32_t *partial, long long per_image, uint32_t *words, int b, hipStream_t stream,
                                const char *fn)
 {

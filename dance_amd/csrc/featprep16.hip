@@ -13,7 +13,8 @@
 //                      in LDS; the 9 taps are immediate offsets into that image.  Output: the
 //                      raw convolution, fp32, channel-blocked [b][c/16][y][x][16] (every wave
 //                      store is 1 KB contiguous), plus per-(image, group) sum / sum of squares
-//                      (fp64 atomics) for the GroupNorm that follows.
+//                      (per-workgroup partial sums, folded in a fixed order: deterministic) for the
+//                      GroupNorm that follows.
 //   k_gn_relu        : GroupNorm + ReLU from those statistics, written either as the next
 //                      convolution's P16 image or as the final NHWC fp32 feature map.
 #include "common.h"
@@ -123,7 +124,9 @@ struct Conv2dArgs {
     const h8 *w;            // [plane][tap ky*3+kx][cin/8][cout] words (ops.pack_conv_weight16)
     float winv;             // 2^-s of the weight scaling
     float *y;               // [b][cout/16][h][w][16] fp32, raw convolution
-    double *stats;          // [b][cout/group_ch][2] sum, sum of squares (zeroed by the host entry)
+    float *partial;         // [b][cout/unit][tiles per image][2]: a workgroup's sum and sum of squares over
+                            // its 128 pixels of every unit = min(group_ch, 16) channels it computes
+                            // (plain stores; k_sum_rows folds them into the GroupNorm statistics)
     int h, w_, cin, cout, group_ch;
 };
 
@@ -297,10 +300,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
         }
         const bool writer = c16 == 0 && (gch >= 16 ? q4 == 0 : (gch >= 8 ? (q4 & 1) == 0 : true));
         if (writer) {
-            const int g = (o0 + 16 * i + 4 * q4) / gch;
-            double *st = a.stats + ((long long)b * (a.cout / gch) + g) * 2;
-            atomicAdd(st, (double)s1);
-            atomicAdd(st + 1, (double)s2);
+            const int unit = gch >= 16 ? 16 : gch, u = (o0 + 16 * i + 4 * q4) / unit;
+            const int tpi = tiles_x * rows2;
+            float *st = a.partial + (((long long)b * (a.cout / unit) + u) * tpi + (bid - b * tpi)) * 2;
+            st[0] = s1;
+            st[1] = s2;
         }
     }
 }
@@ -373,6 +377,41 @@ __global__ __launch_bounds__(256) void k_gn_relu(GnArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------- 1x1 convolution
+// out (b, k, hw) = bias + w (k, c) . x (b, hw, c) for a few output channels k: the edge predictor's
+// last layer (edge_det.py:140-163, applied at :197).  One wave per pixel, a lane holds channels
+// 4 lane + 256 i (16-byte loads), products summed per lane in channel order, then a butterfly over
+// the wave: a fixed order, so the logits -- and the attention map computed from them -- are
+// bit-reproducible (the stock 1x1 convolution is not: a split-K GEMM with atomics).
+__global__ __launch_bounds__(256) void k_conv1x1_nhwc(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, float *__restrict__ out,
+                                                      long long npix, long long hw, int c, int k)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    for (long long p = wave0; p < npix; p += nwaves) {
+        const float *xp = x + p * c;
+        const long long bi = p / hw, pi = p - bi * hw;
+        for (int kk = 0; kk < k; ++kk) {
+            const float *wk = w + (long long)kk * c;
+            float s = 0.0f;
+            for (int ch = 4 * lane; ch < c; ch += 256) {
+                const float4 xv = *reinterpret_cast<const float4 *>(xp + ch);
+                const float4 wv = *reinterpret_cast<const float4 *>(wk + ch);
+                s = fmaf(xv.x, wv.x, s);
+                s = fmaf(xv.y, wv.y, s);
+                s = fmaf(xv.z, wv.z, s);
+                s = fmaf(xv.w, wv.w, s);
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1)
+                s += __shfl_xor(s, m, 64);
+            if (lane == 0)
+                out[(bi * k + kk) * hw + pi] = s + (bias ? bias[kk] : 0.0f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dance_nchw_to_p16img(const float *src, int c_total, int c_off, void *dst16, int b, int c,
@@ -422,9 +461,18 @@ extern "C" int dance_upsample2x_add(const float *src, const float *acc, float *o
     return launch_check(__func__);
 }
 
+extern "C" int64_t dance_conv3x3_16_partial_floats(int b, int cout, int h, int w, int groups)
+{
+    if (b <= 0 || cout <= 0 || h <= 0 || w <= 0 || groups <= 0 || cout % groups)
+        return 0;
+    const int gch = cout / groups, unit = gch >= 16 ? 16 : gch;
+    const long long tpi = (long long)((h + C2_TR - 1) / C2_TR) * ((w + C2_TC - 1) / C2_TC);
+    return (int64_t)b * (cout / unit) * tpi * 2;
+}
+
 extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_scale, float *y_blocked,
-                                double *stats, int b, int cin, int cout, int h, int w, int groups,
-                                void *stream)
+                                double *stats, float *stats_partial, int b, int cin, int cout, int h, int w,
+                                int groups, void *stream)
 {
     DANCE_REQUIRE(b >= 0 && h >= 1 && w >= 1);
     DANCE_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 128 && cout % 128 == 0);
@@ -433,19 +481,23 @@ extern "C" int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_sc
     DANCE_REQUIRE((long long)h * w * (cin / 8) * 2 * 16 < (1ll << 32));      // 32-bit staging offsets
     if (b == 0)
         return 0;
-    DANCE_REQUIRE(x16 && w16 && y_blocked && stats);
+    DANCE_REQUIRE(x16 && w16 && y_blocked && stats && stats_partial);
     Conv2dArgs a;
     a.x = (const _Float16 *)x16; a.w = (const h8 *)w16; a.winv = w_inv_scale; a.y = y_blocked;
-    a.stats = stats; a.h = h; a.w_ = w; a.cin = cin; a.cout = cout; a.group_ch = cout / groups;
-    const long long tiles = (long long)b * ((h + C2_TR - 1) / C2_TR) * ((w + C2_TC - 1) / C2_TC);
+    a.partial = stats_partial; a.h = h; a.w_ = w; a.cin = cin; a.cout = cout; a.group_ch = cout / groups;
+    const long long tpi = (long long)((h + C2_TR - 1) / C2_TR) * ((w + C2_TC - 1) / C2_TC);
+    const long long tiles = (long long)b * tpi;
     DANCE_REQUIRE(tiles * (cout / 128) < (1ll << 31));
-    if (int rc = dance::zero_async(stats, sizeof(double) * 2 * (size_t)b * groups, (hipStream_t)stream, __func__))
-        return rc;
     const size_t lds = 2 * C2_BYTES;
     if (int rc = dance::allow_lds((const void *)k_conv3x3_16, lds, __func__))
         return rc;
     hipLaunchKernelGGL(k_conv3x3_16, dim3((unsigned)(tiles * (cout / 128))), dim3(256), lds, (hipStream_t)stream, a);
-    return launch_check(__func__);
+    if (int rc = launch_check(__func__))
+        return rc;
+    // the statistics: per (image, group) the partials of its units and tiles, contiguous, in a fixed order
+    const int gch = cout / groups, unit = gch >= 16 ? 16 : gch;
+    return dance::sum_rows_async<2>(stats_partial, (long long)b * groups, (gch / unit) * tpi, stats, (hipStream_t)stream,
+                                    __func__);
 }
 
 extern "C" int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamma,
@@ -470,5 +522,19 @@ extern "C" int dance_gn_relu(const float *y_blocked, const double *stats, const 
         return rc;
     if (a.absmax != nullptr)
         return dance::absmax_reduce_async(absmax_partial, (long long)grid.x * grid.y, absmax, b, (hipStream_t)stream, __func__);
+    return launch_check(__func__);
+}
+
+extern "C" int dance_conv1x1_nhwc(const float *x, const float *w, const float *bias, float *out, int b, int h, int w_,
+                                  int c, int k, void *stream)
+{
+    DANCE_REQUIRE(b >= 0 && h >= 1 && w_ >= 1 && c >= 4 && c % 4 == 0 && k >= 1 && k <= 1024);
+    if (b == 0)
+        return 0;
+    DANCE_REQUIRE(x && w && out && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0));
+    const long long hw = (long long)h * w_, npix = hw * b;
+    const long long blocks = (npix + 3) / 4;
+    hipLaunchKernelGGL(k_conv1x1_nhwc, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       x, w, bias, out, npix, hw, c, k);
     return launch_check(__func__);
 }

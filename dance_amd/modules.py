@@ -629,6 +629,17 @@ class EdgeSnakeFPNHead(nn.Module):
         y = head(feat)
         return y if x is None else x + y
 
+    def _predict(self, x):
+        """predictor(x) (edge_det.py:140-163, 197).  Its last layer, a 1x1 convolution to NUM_CLASSES
+        channels, runs as a fixed-order HIP kernel when its input is a channels_last GPU tensor (the HIP
+        conv layers' output): the stock kernel's split-K atomics made two forwards differ in the last bit."""
+        last = self.predictor[-1] if self.strong_feat else self.predictor
+        y = self.predictor[0](x) if self.strong_feat else x
+        if (_ConvNormAct.use_hip and not torch.is_grad_enabled() and ops.is_nhwc(y) and y.size(1) % 4 == 0
+                and os.environ.get("DANCE_FEATPREP", "hip") == "hip"):
+            return ops.conv1x1_nhwc(y, last.weight, last.bias)
+        return last(y)
+
     def forward(self, features, pred_instances=None, targets=None):
         if self.training:
             raise NotImplementedError("dance_amd.EdgeSnakeFPNHead is inference-only (call .eval())")
@@ -637,7 +648,7 @@ class EdgeSnakeFPNHead(nn.Module):
             for f, head in zip(self.in_features, self.scale_heads):
                 x = self._add_scale_head(head, features[f], x)
         with timer.env("edge"):
-            pred_edge = self.predictor(x).sigmoid()
+            pred_edge = self._predict(x).sigmoid()
             att_map = self.attender(1 - pred_edge) if self.attention else None
         feats = x if self.strong_feat else features["p2"]
         snake_input = (att_map, feats) if self.attention else feats

@@ -428,6 +428,8 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
     x16 = torch.empty((b, 2, c // 8, h, w, 8), dtype=torch.float16, device=dev)
     yb = torch.empty((b, c // 16, h, w, 16), dtype=torch.float32, device=dev)
     stats = torch.empty((b, groups, 2), dtype=torch.float64, device=dev)
+    spart = torch.empty((max(1, int(lib().dance_conv3x3_16_partial_floats(b, c, h, w, groups))),), dtype=torch.float32,
+                        device=dev)
     out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
     words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=dev)
     partial = _absmax_partial(ABSMAX_OF_GN_RELU, b, c, h * w, dev)
@@ -438,7 +440,7 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
         for i, (w16, scale, gamma, beta) in enumerate(layers):
             if w16.shape[2] * 8 != c or w16.shape[3] != c:
                 raise ValueError("bottom_out layers are C -> C")
-            check(lib().dance_conv3x3_16(ptr(x16), ptr(w16), 1.0 / scale, ptr(yb), ptr(stats), b, c, c, h, w,
+            check(lib().dance_conv3x3_16(ptr(x16), ptr(w16), 1.0 / scale, ptr(yb), ptr(stats), ptr(spart), b, c, c, h, w,
                                          groups, st), "conv3x3_16")
             last = i + 1 == len(layers)
             check(lib().dance_gn_relu(ptr(yb), ptr(stats), ptr(gamma), ptr(beta), eps, groups,
@@ -468,6 +470,22 @@ def upsample2x_add(src, acc=None, inplace=False):
     with torch.cuda.device(src.device):
         check(lib().dance_upsample2x_add(ptr(src), ptr(acc), ptr(out), b, h, w, c, current_stream()),
               "upsample2x_add")
+    return out
+
+
+def conv1x1_nhwc(x, weight, bias=None):
+    """nn.Conv2d(C, K, 1) on a channels_last fp32 GPU tensor (B,C,H,W), summed in a fixed order
+    (dance_conv1x1_nhwc): -> (B,K,H,W) contiguous.  The edge predictor's last layer (edge_det.py:197)."""
+    if not is_nhwc(x):
+        raise RuntimeError("conv1x1_nhwc: a channels_last fp32 GPU tensor expected")
+    b, c, h, w = x.shape
+    k = weight.shape[0]
+    wt = weight.detach().reshape(k, c).float().contiguous()
+    bs = None if bias is None else bias.detach().float().contiguous()
+    out = torch.empty((b, k, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().dance_conv1x1_nhwc(ptr(x), ptr(wt), ptr(bs), ptr(out), b, h, w, c, k, current_stream()),
+              "conv1x1_nhwc")
     return out
 
 

@@ -150,10 +150,13 @@ int dance_upsample2x_add(const float *src, const float *acc, float *out, int b, 
 /* dance_conv3x3_16: raw 3x3 convolution (zero padding 1, no bias) of a P16 image with weights
  *   packed [plane][tap ky*3+kx][cin/8][cout][8] fp16 of w * 2^s (w_inv_scale = 2^-s).
  *   y_blocked (b, cout/16, h, w, 16) fp32; stats (b, groups, 2) f64 = per-group sum and sum of
- *   squares of y (zeroed here, on the stream). */
+ *   squares of y, summed in a fixed order (no atomics: two forwards give identical bits) from the
+ *   workgroups' partial sums in stats_partial, dance_conv3x3_16_partial_floats(...) floats of
+ *   scratch. */
+int64_t dance_conv3x3_16_partial_floats(int b, int cout, int h, int w, int groups);
 int dance_conv3x3_16(const void *x16, const void *w16, float w_inv_scale, float *y_blocked,
-                     double *stats, int b, int cin, int cout, int h, int w, int groups,
-                     void *stream);
+                     double *stats, float *stats_partial, int b, int cin, int cout, int h, int w,
+                     int groups, void *stream);
 /* dance_gn_relu: GroupNorm(groups, eps) * gamma + beta, then ReLU, of y_blocked using stats;
  *   exactly one of out16 (P16 image, the next layer's input) / out_nhwc ((b, h, w, c) fp32,
  *   what the gather kernels read) is non-null.  absmax (with out_nhwc; may be NULL): the
@@ -163,6 +166,13 @@ int dance_gn_relu(const float *y_blocked, const double *stats, const float *gamm
                   const float *beta, float eps, int groups, void *out16, float *out_nhwc,
                   uint32_t *absmax, uint32_t *absmax_partial, int b, int c, int h, int w,
                   void *stream);
+
+/* dance_conv1x1_nhwc: out (b, k, h, w) = bias (k, or NULL) + w (k, c) . x (b, h, w, c) NHWC fp32, a 1x1
+ *   convolution to a few output channels summed in a fixed order (bit-reproducible, unlike the
+ *   stock split-K kernels): the edge predictor's last layer, edge_det.py:140-163 applied at :197.
+ *   c % 4 == 0, x and w 16-byte aligned. */
+int dance_conv1x1_nhwc(const float *x, const float *w, const float *bias, float *out, int b, int h,
+                       int w_, int c, int k, void *stream);
 
 /* ------------------------------------ attention-map producer ------ */
 /* reference: EdgeSnakeFPNHead.attender, core/modeling/edge_snake/edge_det.py:66-100, applied

@@ -118,3 +118,34 @@ def test_upsample2x_add_vs_torch(device, shape):
     assert out.data_ptr() == acc.data_ptr() and torch.equal(out, got) and not torch.equal(acc, keep)
     with pytest.raises(RuntimeError):
         ops.upsample2x_add(src.contiguous() if h * w > 1 and c > 1 else src.cpu())
+
+
+def test_bottom_out_is_bit_reproducible(device):
+    """the GroupNorm statistics are per-workgroup partial sums folded in a fixed order (no atomics):
+    repeated runs over a map of a few thousand workgroups give identical bits, statistics included"""
+    cfg, sd, _ = _state_dict(11)
+    feats = synthetic.make_features(2, 256, 100, 152, 123, attention=True).to(device)
+    layers = _layers(sd, device)
+    first = ops.bottom_out16(feats, 1, layers)
+    for _ in range(4):
+        assert torch.equal(ops.bottom_out16(feats, 1, layers), first)
+    assert torch.equal(ops.absmax_of(ops.bottom_out16(feats, 1, layers)), ops.absmax_of(first))
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 48, 64, 1), (1, 128, 5, 7, 3), (3, 260, 9, 4, 2), (1, 4, 1, 1, 1)])
+def test_conv1x1_nhwc_vs_torch(device, shape):
+    """the edge predictor's last layer (edge_det.py:197) as a fixed-order kernel: against F.conv2d, with and
+    without bias, and bit-identical from run to run"""
+    b, c, h, w, k = shape
+    g = torch.Generator().manual_seed(c + k)
+    x = torch.randn((b, c, h, w), generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    if not ops.is_nhwc(x):          # (1x1 maps: every layout is dense)
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    wt = (torch.randn((k, c, 1, 1), generator=g) / c ** 0.5).to(device)
+    bias = torch.randn((k,), generator=g).to(device)
+    for bs in (bias, None):
+        got = ops.conv1x1_nhwc(x, wt, bs)
+        want = torch.nn.functional.conv2d(x.double(), wt.double(), None if bs is None else bs.double())
+        assert got.shape == (b, k, h, w) and got.is_contiguous()
+        assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+        assert torch.equal(ops.conv1x1_nhwc(x, wt, bs), got)

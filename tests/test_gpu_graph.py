@@ -1,7 +1,8 @@
 """GPU: the one-image head as one HIP-graph replay (dance_amd/graph.py) reproduces the eager
-forward for the real detections, for changing inputs and detection counts on the same graph.
-Not to the bit: the feature-prep layers' GroupNorm statistics are fp64 ATOMIC sums (order varies
-from run to run, eager included), so the comparison allows the eager forward's own spread."""
+forward for the real detections, for changing inputs and detection counts on the same graph --
+to the bit: nothing on the path sums in an order that varies (the feature-prep layers' GroupNorm
+statistics are per-workgroup partials folded in a fixed order, csrc/common.h k_sum_rows), so two
+eager forwards are identical too (SURVEY section 5's run-twice check)."""
 import pytest
 import torch
 
@@ -34,11 +35,12 @@ def test_graphed_head_equals_eager(device):
             att_e, _, res = head(feats, [Instances((h, w), pred_boxes=Boxes(boxes.clone()))], None)
             att_e2, _, res2 = head(feats, [Instances((h, w), pred_boxes=Boxes(boxes.clone()))], None)
         want, want2 = res[0].pred_polys.tensor, res2[0].pred_polys.tensor
-        # a box clipped to zero width is a NaN contour in the reference and here (derange): same places
-        assert torch.equal(torch.isnan(polys_g), torch.isnan(want))
-        z = lambda t: torch.nan_to_num(t, nan=0.0)                      # noqa: E731
-        spread = float((z(want) - z(want2)).abs().max())
-        assert float((att_g - att_e).abs().max()) <= 1e-5
-        assert float((z(polys_g) - z(want)).abs().max()) <= max(5e-3, 4 * spread)
+        # run twice, compare bits: attention map and contours (a box clipped to zero width is a NaN contour
+        # in the reference and here -- derange -- at the same places)
+        assert torch.equal(att_e, att_e2)
+        assert torch.equal(want.view(torch.int32), want2.view(torch.int32))
+        # and the graph replays exactly what eager computes
+        assert torch.equal(att_g, att_e)
+        assert torch.equal(polys_g.view(torch.int32), want.view(torch.int32))
         assert bool(torch.isfinite(polys_g).any())
     assert len(g._graphs) == 1
