@@ -28,7 +28,9 @@ ARCH = "gfx950"
 # (-Xarch_device does not forward -Xclang: the host pass sees the feature too and says it ignores it;
 # _compile drops that line.)
 NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# --offload-compress: the gfx950 code objects are stored zstd-compressed inside the fat binary (the HIP
+# runtime of ROCm >= 6.1 inflates them when the library is loaded): libdance_hip.so 3.0 -> ~1 MB
+COMMON = ["--offload-arch=" + ARCH, "--offload-compress", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math"] + NOPK
 # (source, extra flags).  The "exact" files round every fp32 op separately so that indices
 # and resampled coordinates are bit-identical to the reference's op sequence.
@@ -71,7 +73,39 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 PACKED_FP32 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")
 
 
-def device_isa_counts(so_path=OUT, patterns=PACKED_FP32 + ("v_mfma_f32",)):
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+OBJCOPY = "/opt/rocm/lib/llvm/bin/llvm-objcopy"
+
+
+def device_code_objects(so_path, out_dir):
+    """Write every gfx950 code object bundled in `so_path` to `out_dir` and return the paths.  The
+    .hip_fatbin section holds one offload bundle per translation unit, zstd-compressed ("CCOB" header:
+    magic, u16 version, u16 method, total size, ...) when built with --offload-compress, plain
+    ("__CLANG_OFFLOAD_BUNDLE__") otherwise; clang-offload-bundler unpacks either."""
+    import re
+    import struct
+    fat = os.path.join(out_dir, "fat.bin")
+    subprocess.check_call([OBJCOPY, "--dump-section", ".hip_fatbin=" + fat, so_path, os.path.join(out_dir, "stripped.so")])
+    data = open(fat, "rb").read()
+    starts = sorted(m.start() for m in re.finditer(b"CCOB|__CLANG_OFFLOAD_BUNDLE__", data))
+    objs = []
+    for i, p in enumerate(starts):
+        end = starts[i + 1] if i + 1 < len(starts) else len(data)
+        if data[p:p + 4] == b"CCOB":
+            version = struct.unpack_from("<H", data, p + 4)[0]
+            total = struct.unpack_from("<Q" if version >= 3 else "<I", data, p + 8)[0]
+            end = p + total
+        piece, co = os.path.join(out_dir, "bundle%d.bin" % i), os.path.join(out_dir, "bundle%d.co" % i)
+        with open(piece, "wb") as f:
+            f.write(data[p:end])
+        subprocess.check_call([BUNDLER, "--unbundle", "--type=o", "--input=" + piece, "--output=" + co,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        objs.append(co)
+    return objs
+
+
+def device_isa_counts(so_path=OUT, patterns=PACKED_FP32 + ("v_mfma_f32", "scratch_")):
     """Disassemble every gfx950 code object bundled in `so_path` and count the instructions whose
     mnemonic starts with one of `patterns`.  The guard behind NOPK: the flag is a compiler
     feature switch that a later toolchain may stop honouring (its host-pass warning is filtered
@@ -80,15 +114,12 @@ def device_isa_counts(so_path=OUT, patterns=PACKED_FP32 + ("v_mfma_f32",)):
     import tempfile
     tmp = tempfile.mkdtemp(prefix="dance_isa_")
     try:
-        so = os.path.join(tmp, os.path.basename(so_path))
-        shutil.copy(so_path, so)            # llvm-objdump --offloading extracts next to its input
-        subprocess.check_call([OBJDUMP, "--offloading", so], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        objs = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
+        objs = device_code_objects(so_path, tmp)
         if not objs:
             raise RuntimeError("no gfx950 code object found in %s" % so_path)
         counts = {p: 0 for p in patterns}
         for f in objs:
-            text = subprocess.run([OBJDUMP, "-d", "--mcpu=" + ARCH, os.path.join(tmp, f)], check=True,
+            text = subprocess.run([OBJDUMP, "-d", "--mcpu=" + ARCH, f], check=True,
                                   stdout=subprocess.PIPE, text=True).stdout
             for line in text.splitlines():
                 parts = line.split()
