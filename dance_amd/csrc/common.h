@@ -118,9 +118,17 @@ static __global__ __launch_bounds__(256) void k_absmax_reduce(const uint32_t *__
                                                               uint32_t *__restrict__ words)
 {
     const uint32_t *p = partial + (long long)blockIdx.x * per_image;
-    unsigned m = 0;
-    for (long long i = threadIdx.x; i < per_image; i += 256)
-        m = max(m, p[i]);
+    unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;        // four loads in flight per thread
+    long long i = threadIdx.x;
+    for (; i + 768 < per_image; i += 1024) {
+        m0 = max(m0, p[i]);
+        m1 = max(m1, p[i + 256]);
+        m2 = max(m2, p[i + 512]);
+        m3 = max(m3, p[i + 768]);
+    }
+    for (; i < per_image; i += 256)
+        m0 = max(m0, p[i]);
+    unsigned m = max(max(m0, m1), max(m2, m3));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1)
         m = max(m, (unsigned)__shfl_xor((int)m, s, 64));

@@ -109,7 +109,7 @@ class _ConvNormAct(nn.Conv2d):
                 and os.environ.get("DANCE_PRECISION", "fp16x3") == "fp16x3"):
             layer = self.hip_layer(x.device)
             if layer is not None:
-                return ops.bottom_out16(x, 0, [layer], groups=32, eps=self.norm.eps).permute(0, 3, 1, 2)
+                return ops.bottom_out16(x, 0, [layer], groups=32, eps=self.norm.eps, measure=False).permute(0, 3, 1, 2)
         x = super().forward(x)
         if self.norm is not None:
             x = self.norm(x)

@@ -406,13 +406,15 @@ def pack_conv3x3_weight16(weight):
     return pack_conv_weight16(weight.reshape(cout, cin, 9))
 
 
-def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
+def bottom_out16(features, c_off, layers, groups=32, eps=1e-5, measure=True):
     """`RefineNet.bottom_out` (snake_head.py:562-615, 1816-1820): for every layer
     Conv2d 3x3 (pad 1, no bias) -> GroupNorm(groups) -> ReLU, in the fast-mode arithmetic.
 
     features (B, c_off + C, H, W) fp32 NCHW (channels before c_off, e.g. the attention map,
     are skipped); layers = [(w16, scale_pow2, gamma, beta), ...] with w16 from
-    `pack_conv3x3_weight16`.  Returns the NHWC fp32 map (B, H, W, C) the gather kernels read."""
+    `pack_conv3x3_weight16`.  Returns the NHWC fp32 map (B, H, W, C) the gather kernels read;
+    measure: it carries its per-image max |value| words (`absmax_of`), measured on the way out --
+    switch off for a layer whose output does not go to the deformer."""
     _need_gpu(features)
     # a channels_last tensor (what this function's own output viewed as NCHW, an upsampling or a
     # sum of such tensors is) is read in place: no NCHW copy between the layers of a head
@@ -431,8 +433,10 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
     spart = torch.empty((max(1, int(lib().dance_conv3x3_16_partial_floats(b, c, h, w, groups))),), dtype=torch.float32,
                         device=dev)
     out = torch.empty((b, h, w, c), dtype=torch.float32, device=dev)
-    words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=dev)
-    partial = _absmax_partial(ABSMAX_OF_GN_RELU, b, c, h * w, dev)
+    words = partial = None
+    if measure:
+        words = torch.empty((b, ABSMAX_WORDS), dtype=torch.int32, device=dev)
+        partial = _absmax_partial(ABSMAX_OF_GN_RELU, b, c, h * w, dev)
     with torch.cuda.device(dev):
         st = current_stream()
         to_p16 = lib().dance_nhwc_to_p16img if nhwc_in else lib().dance_nchw_to_p16img
@@ -447,7 +451,8 @@ def bottom_out16(features, c_off, layers, groups=32, eps=1e-5):
                                       None if last else ptr(x16), ptr(out) if last else None,
                                       ptr(words) if last else None, ptr(partial) if last else None, b, c, h, w, st),
                   "gn_relu")
-    setattr(out, ABSMAX_ATTR, words)
+    if measure:
+        setattr(out, ABSMAX_ATTR, words)
     return out
 
 
