@@ -8,8 +8,9 @@ edge predictor, attender, bottom_out, contour sampling, three snake iterations -
 once per input shape and replayed.  Static shapes are obtained by padding the detections to
 `max_instances` (FCOSE keeps at most POST_NMS_TOPK_TEST = 100 per image, defaults.py:216) with a
 dummy box; every contour depends only on its own box and the image's features, so the
-real instances' results equal the eager forward's within its own run-to-run spread (the feature
-prep's GroupNorm statistics are fp64 atomic sums; tests/test_gpu_graph.py).
+real instances' results equal the eager forward's bit for bit (nothing on the path sums in an order
+that varies; tests/test_gpu_graph.py).  The forward's forks onto side HIP streams (low-resolution
+pyramid levels, edge / attention branch: modules.EdgeSnakeFPNHead) become parallel branches of the graph.
 """
 import torch
 

@@ -326,6 +326,9 @@ class RefineNet(_SnakeHeadBase):
             streams = 1
         else:
             streams = 2
+        wait_for = getattr(self, "_wait_for", None)
+        if wait_for is not None:                 # the attention map is being produced on another stream (EdgeSnakeFPNHead)
+            torch.cuda.current_stream(nhwc.device).wait_stream(wait_for)
         with timer.env("snake_deformation"):
             return d.deform((nhwc, att), locations, image_idx, image_sizes, whs, layout="nhwc", streams=streams)
 
@@ -612,22 +615,32 @@ class EdgeSnakeFPNHead(nn.Module):
         self.refine_head = RefineNet(cfg, polygon_cls=polygon_cls)
 
     @staticmethod
-    def _add_scale_head(head, feat, x):
-        """x + head(feat) (edge_det.py:188-194).  When the head ends in its x2 upsampling and both
-        sides are channels_last GPU tensors (the HIP conv layers' output), that upsampling and the
-        sum are one launch, written into x."""
+    def _hip_upsample_ok():
+        return (_ConvNormAct.use_hip and not torch.is_grad_enabled()
+                and os.environ.get("DANCE_FEATPREP", "hip") == "hip")
+
+    @classmethod
+    def _scale_head_front(cls, head, feat):
+        """A scale head up to, not including, an x2 upsampling it ends in (edge_det.py:106-138) ->
+        (y, the pending nn.Upsample or None)."""
         mods = list(head)
-        if (x is not None and isinstance(mods[-1], nn.Upsample) and _ConvNormAct.use_hip and feat.is_cuda
-                and not torch.is_grad_enabled() and os.environ.get("DANCE_FEATPREP", "hip") == "hip"):
+        if isinstance(mods[-1], nn.Upsample) and feat.is_cuda and cls._hip_upsample_ok():
             y = feat
             for m in mods[:-1]:
                 y = m(y)
-            if (ops.is_nhwc(y) and ops.is_nhwc(x) and y.size(1) % 4 == 0
-                    and tuple(x.shape) == (y.size(0), y.size(1), 2 * y.size(2), 2 * y.size(3))):
-                return ops.upsample2x_add(y, x, inplace=True)
-            return x + mods[-1](y)
-        y = head(feat)
-        return y if x is None else x + y
+            return y, mods[-1]
+        return head(feat), None
+
+    @staticmethod
+    def _scale_head_join(x, y, up):
+        """x + up(y) (edge_det.py:188-194).  When both sides are channels_last GPU tensors (the HIP conv
+        layers' output) the pending upsampling and the sum are one launch, written into x."""
+        if up is None:
+            return y if x is None else x + y
+        if (x is not None and ops.is_nhwc(y) and ops.is_nhwc(x) and y.size(1) % 4 == 0
+                and tuple(x.shape) == (y.size(0), y.size(1), 2 * y.size(2), 2 * y.size(3))):
+            return ops.upsample2x_add(y, x, inplace=True)
+        return up(y) if x is None else x + up(y)
 
     def _predict(self, x):
         """predictor(x) (edge_det.py:140-163, 197).  Its last layer, a 1x1 convolution to NUM_CLASSES
@@ -640,19 +653,66 @@ class EdgeSnakeFPNHead(nn.Module):
             return ops.conv1x1_nhwc(y, last.weight, last.bias)
         return last(y)
 
+    # Few images (the reference's inference mode is ONE image per GPU, dance.py:52): the kernels of the
+    # low-resolution pyramid levels (250, 78 and 28 workgroups on 256 CUs) and of the edge / attention
+    # branch leave most of the chip idle, and nothing orders them against the full-resolution convolutions
+    # they run beside in the data-flow graph -- so they go to HIP streams of their own:
+    #   side 0..k   scale heads of p3.. up to their last upsampling    ||  main: scale head of p2
+    #   main        the x2 upsample + sum of every level (in the reference's order: same bits)
+    #   side edge   predictor -> sigmoid -> attender                   ||  main: refine_head's bottom_out
+    #   main        waits for the attention map right before the first gather.
+    # Under stream capture (dance_amd/graph.py) the forks become parallel branches of the HIP graph.
+    OVERLAP_MAX_IMAGES = 2
+
+    def _side_streams(self, dev, k):
+        cache = getattr(self, "_streams", None)
+        if cache is None or cache[0] != dev or len(cache[1]) < k:
+            self._streams = cache = (dev, [torch.cuda.Stream(dev) for _ in range(k)])
+        return cache[1][:k]
+
     def forward(self, features, pred_instances=None, targets=None):
         if self.training:
             raise NotImplementedError("dance_amd.EdgeSnakeFPNHead is inference-only (call .eval())")
+        first = features[self.in_features[0]]
+        overlap = (first.is_cuda and first.size(0) <= self.OVERLAP_MAX_IMAGES and self._hip_upsample_ok()
+                   and os.environ.get("DANCE_STREAMS", "") != "1")
+        if not overlap:
+            with timer.env("pfpn_back"):
+                x = None
+                for f, head in zip(self.in_features, self.scale_heads):
+                    x = self._scale_head_join(x, *self._scale_head_front(head, features[f]))
+            with timer.env("edge"):
+                pred_edge = self._predict(x).sigmoid()
+                att_map = self.attender(1 - pred_edge) if self.attention else None
+            feats = x if self.strong_feat else features["p2"]
+            snake_input = (att_map, feats) if self.attention else feats
+            new_instances, _ = self.refine_head(snake_input, pred_instances, None)
+            return (att_map if self.attention else pred_edge), {}, new_instances
+        cur = torch.cuda.current_stream(first.device)
+        sides = self._side_streams(first.device, len(self.in_features))
         with timer.env("pfpn_back"):
-            x = None
-            for f, head in zip(self.in_features, self.scale_heads):
-                x = self._add_scale_head(head, features[f], x)
-        with timer.env("edge"):
+            fronts = []
+            for st, f, head in zip(sides[1:], self.in_features[1:], self.scale_heads[1:]):
+                st.wait_stream(cur)                                 # (the inputs exist; the previous forward is done with this stream's buffers)
+                with torch.cuda.stream(st):
+                    fronts.append(self._scale_head_front(head, features[f]))
+            x = self._scale_head_join(None, *self._scale_head_front(self.scale_heads[0], first))
+            for st, (y, up) in zip(sides[1:], fronts):
+                cur.wait_stream(st)
+                x = self._scale_head_join(x, y, up)
+        edge = sides[0]
+        edge.wait_stream(cur)
+        with timer.env("edge"), torch.cuda.stream(edge):
             pred_edge = self._predict(x).sigmoid()
             att_map = self.attender(1 - pred_edge) if self.attention else None
         feats = x if self.strong_feat else features["p2"]
         snake_input = (att_map, feats) if self.attention else feats
-        new_instances, _ = self.refine_head(snake_input, pred_instances, None)
+        self.refine_head._wait_for = edge                        # joined right before the deformation reads the map
+        try:
+            new_instances, _ = self.refine_head(snake_input, pred_instances, None)
+        finally:
+            self.refine_head._wait_for = None
+            cur.wait_stream(edge)                                # (also when refine_head returned early: no instances)
         return (att_map if self.attention else pred_edge), {}, new_instances
 
 

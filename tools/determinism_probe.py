@@ -31,7 +31,7 @@ def stages():
             out["sum after " + f] = x.clone()
         x2 = None
         for f, hd in zip(head.in_features, head.scale_heads):
-            x2 = head._add_scale_head(hd, feats[f], x2)
+            x2 = head._scale_head_join(x2, *head._scale_head_front(hd, feats[f]))
         out["fused sum"] = x2.clone()
         p0 = head.predictor[0](x2)
         out["predictor.0"] = p0.clone()
