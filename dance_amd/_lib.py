@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DANCE_HIP_LIB: load another build of the same library (A/B kernel experiments)
 SO_PATH = os.environ.get("DANCE_HIP_LIB") or os.path.join(_HERE, "libdance_hip.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 EVOLVE_EVENTS = 14          # DANCE_EVOLVE_EVENTS
 STAGE_NAMES = ("head", "res0", "res1", "res2", "res3", "res4", "res5", "res6", "fusion_max",
                "row_constant", "pred0", "pred1", "offset_update")
@@ -56,10 +56,11 @@ class SnakeNet16Struct(ctypes.Structure):
 class PolicyStruct(ctypes.Structure):
     """Mirror of `dance_policy` (include/dance_hip.h); the defaults are the library's."""
 
-    _fields_ = [("few_contour_forms", c_int), ("fuse_tail_split", c_int), ("tail_group", c_int)]
+    _fields_ = [("few_contour_forms", c_int), ("fuse_tail_split", c_int), ("tail_group", c_int),
+                ("coop_stack", c_int)]
 
-    def __init__(self, few_contour_forms=1, fuse_tail_split=1, tail_group=0):
-        super().__init__(int(few_contour_forms), int(fuse_tail_split), int(tail_group))
+    def __init__(self, few_contour_forms=1, fuse_tail_split=1, tail_group=0, coop_stack=1):
+        super().__init__(int(few_contour_forms), int(fuse_tail_split), int(tail_group), int(coop_stack))
 
 
 ABSMAX_WORDS = 8            # DANCE_ABSMAX_WORDS
@@ -146,7 +147,7 @@ SIGNATURES = {
     "dance_gather_head16w": (c_int, [P, P, P, P, P, P, P, c_float, c_float, P, P, P, c_int64, P, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, POINTER(PolicyStruct), P]),
     "dance_res_stack16": (c_int, [POINTER(SnakeNet16Struct), P, c_int64, c_int64, c_int, c_int, c_int,
-                                  POINTER(PolicyStruct), P]),
+                                  POINTER(PolicyStruct), P, P]),
     "dance_init_head16": (c_int, [P, P, P, P, c_float, P, P, P, P, P, c_float, c_float, P, P, P, c_int64, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "dance_snake_init16": (c_int, [POINTER(SnakeNet16Struct), POINTER(InitFuse16Struct), P, P, P, P, P,

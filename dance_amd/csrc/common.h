@@ -241,6 +241,7 @@ inline dance_policy policy_or_default(const dance_policy *p)
     d.few_contour_forms = 1;
     d.fuse_tail_split = 1;
     d.tail_group = 0;
+    d.coop_stack = 1;
     return p ? *p : d;
 }
 

@@ -18,7 +18,7 @@ char *error_buffer() { return g_error; }
 using dance::ceil_div;
 using dance::launch_check;
 
-extern "C" int dance_abi_version(void) { return 15; }
+extern "C" int dance_abi_version(void) { return 16; }
 extern "C" const char *dance_last_error(void) { return dance::error_buffer(); }
 
 extern "C" int dance_device_info(int *cu_count_host, int *lds_bytes_host)

@@ -447,6 +447,251 @@ __global__ __launch_bounds__(512) void k_res_stack16w13(Stack16Args a, int n)
     res_stack16w_body<RT, RT - 1, TERMS>(a, n);
 }
 
+// The residual stack for FEW contours (the reference's published mode: one image, <= 100 instances on
+// 256 CUs, dance.py:52): a contour's blocks on TWO workgroups, i.e. two CUs.  The workgroups of a pair
+// split the 128 output channels (64 each = one 64-channel chunk image); block l + 1 needs all 128, so
+// after every block but the last the halves are exchanged: a workgroup writes its half of state slot
+// l + 1 (it goes to HBM for the fusion kernel anyway) with device-scope stores, waits until they
+// have left the CU, raises its flag to l + 1, waits for the partner's flag, and reloads the
+// partner's chunk image from the slot with device-scope loads.  (Agent-scope FENCES instead --
+// __threadfence -- write back and invalidate whole caches: 0.42 ms for the stack at 100 contours
+// against 0.13 ms on one workgroup each.)  Same products and summation order per output element as k_res_stack16w / 16s:
+// bit-identical results.
+//
+// Hang safety.  (1) Pairing: workgroup ids p and p + 8 inside a group of 16 (same XCD under the
+// round-robin dispatch, so the exchange stays in one L2; correctness does not depend on it), and the
+// dispatcher starts a kernel's workgroups in order -- a resident workgroup's partner is at most 8
+// places behind it in the queue, so whenever 16 slots are free for this kernel a complete pair runs.
+// (2) The wait is bounded by the constant 100 MHz clock (COOP_WAIT_TICKS = 2 s): on expiry the
+// workgroup raises the status word, stops waiting for the rest of the contour, fills its half of the
+// last slot with NaN (the contour comes out NaN: loud) and finishes -- the grid always drains.
+// coop: [0] status (0 = ok), [16 + 2 * contour + half] flags; zeroed by the host entry before the launch.
+constexpr long long COOP_WAIT_TICKS = 200000000ll;
+
+// The contraction of one 64-channel chunk image for a wave that owns 2 row tiles x 2 vertex tiles, with
+// the 9 taps x 2 steps fully unrolled so that the weights can be prefetched AD - 1 steps ahead across
+// tap boundaries (mfma16_core_sw's rotation closes over a tap: one step ahead at 2 steps per tap).
+// With a contour per workgroup pair and nothing else on the CU, the latency of the weight fetches
+// from L2 -- not the matrix pipe -- is what the loop waits for.  Same products in the same order per
+// output element as mfma16_core_sw: bit-identical.
+#ifndef DANCE_COOP_AD
+#define DANCE_COOP_AD 6
+#endif
+template <int TERMS>
+__device__ __forceinline__ void coop_core(f32x4 (&acc)[2][2], const char *xs, unsigned lds0, int v, const char *wchunk,
+                                          unsigned wlane, long long wps_b, long long wts_b, long long wstep_b, int dilation,
+                                          int c16, int q4, int j0)
+{
+    constexpr int CT = 2, NST = 2, TAPS = 9, NG = TAPS * NST, AD = DANCE_COOP_AD, D = AD - 1;
+    using G = Geo<4, 8>;
+    constexpr int SSTEP = 4 * G::VP * 16;
+    const unsigned rowb = lds0 + q4 * G::VP * 16;
+    const unsigned lim = rowb + v * 16, d16 = dilation * 16, v16 = v * 16;
+    unsigned p[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+        p[j] = rowb + ring16((j0 + j) * 16 + c16, -(TAPS >> 1) * dilation, v) * 16;
+    h8 ah[AD][2], al[AD][2], bh[2][CT], bl[2][CT];
+#define COOP_LOAD_A(G_)                                                                               \
+    do {                                                                                              \
+        const char *pa_ = wchunk + ((G_) / NST) * wts_b + ((G_) % NST) * wstep_b;                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                            \
+            ah[(G_) % AD][i_] = *reinterpret_cast<const h8 *>(pa_ + wlane + i_ * 256);                \
+            if constexpr (TERMS == 3)                                                                 \
+                al[(G_) % AD][i_] = *reinterpret_cast<const h8 *>(pa_ + wps_b + wlane + i_ * 256);    \
+        }                                                                                             \
+    } while (0)
+#define COOP_LOAD_B(G_)                                                                               \
+    do {                                                                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < CT; ++j_) {                                           \
+            bh[(G_) % 2][j_] = *reinterpret_cast<const h8 *>(xs + p[j_] + ((G_) % NST) * SSTEP);      \
+            if constexpr (TERMS == 3)                                                                 \
+                bl[(G_) % 2][j_] = *reinterpret_cast<const h8 *>(xs + p[j_] + ((G_) % NST) * SSTEP + G::PLANE); \
+            if ((G_) % NST == NST - 1) {                                                              \
+                const unsigned tpos_ = p[j_] + d16;                                                   \
+                p[j_] = tpos_ >= lim ? tpos_ - v16 : tpos_;                                           \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+    dance::static_for<0, D>([&](auto g) __attribute__((always_inline)) { COOP_LOAD_A(decltype(g)::value); });
+    COOP_LOAD_B(0);
+    dance::static_for<0, NG>([&](auto gg) __attribute__((always_inline)) {
+        constexpr int g = decltype(gg)::value;
+        if constexpr (g + D < NG)
+            COOP_LOAD_A(g + D);
+        if constexpr (g + 1 < NG)
+            COOP_LOAD_B(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if constexpr (TERMS == 3) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g % AD][0], bh[g % 2][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g % AD][1], bh[g % 2][j], acc[1][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][0], bl[g % 2][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][1], bl[g % 2][j], acc[1][j], 0, 0, 0);
+            }
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][0], bh[g % 2][j], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][1], bh[g % 2][j], acc[1][j], 0, 0, 0);
+        }
+    });
+#undef COOP_LOAD_A
+#undef COOP_LOAD_B
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(512) void k_res_stack16c(Stack16Args a, int n, int *coop)
+{
+    constexpr int RT = 4, CBC = 8, NW = 8, CTW = 2;
+    using G = Geo<RT, CBC>;
+    using S = StageGeo<RT, CBC, NW>;
+    extern __shared__ __attribute__((aligned(16))) char xs[];   // chunk images 0 | 1 = channels 0..63 | 64..127
+    __shared__ int gave_up;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int within = blockIdx.x & 15, half = within >> 3;
+    const long long nn = (long long)(blockIdx.x >> 4) * 8 + (within & 7);
+    if (nn >= n)
+        return;                                 // (both workgroups of a pair leave together)
+    const int o0 = 64 * half + 32 * (wave & 1), j0 = CTW * (wave >> 1);
+    const int v = a.v;
+    const long long wbs_b = 128 * 16, wts_b = 16 * wbs_b, wps_b = 9 * wts_b;
+    const unsigned wlane = (unsigned)(q4 * 128 + c16) * 16u;
+    _Float16 *sn = a.state + nn * a.stride;
+    int *my_flag = coop + 16 + 2 * nn + half, *partner_flag = coop + 16 + 2 * nn + (half ^ 1);
+    if (t == 0)
+        gave_up = 0;
+    {
+        u32x4 sreg[S::N];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            stage_load<RT, CBC, NW>(sreg, 0, S::N, reinterpret_cast<const char *>(sn) + (long long)c * CBC * v * 16, v,
+                                    wave, lane);
+            stage_commit<RT, CBC, NW>(sreg, xs, c * G::BYTES, v, wave, lane);
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < a.nlayers; ++l) {
+        f32x4 acc[2][CTW];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias_s[l] + o0 + 16 * i + 4 * q4);
+            const f32x4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int j = 0; j < CTW; ++j)
+                acc[i][j] = bv;
+        }
+        const char *wl = reinterpret_cast<const char *>(a.w[l]) + (long long)o0 * 16;
+        const int dil = a.dilation[l];
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c)
+            coop_core<TERMS>(acc, xs, c * G::BYTES, v, wl + (long long)c * CBC * wbs_b, wlane, wps_b, wts_b, 4 * wbs_b, dil,
+                             c16, q4, j0);
+        __syncthreads();                        // every wave has read the whole image
+        int ce = c16, qe = q4;
+        asm volatile("" : "+v"(ce), "+v"(qe));
+        _Float16 *yslot = sn + (l + 1) * a.slot;
+        const float winv = a.winv[l], rmul = a.rmul[l];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int ob = o0 + 16 * i2 + 4 * qe;
+            const float4 sc4 = *reinterpret_cast<const float4 *>(a.scale[l] + ob);
+            const float4 sh4 = *reinterpret_cast<const float4 *>(a.shift[l] + ob);
+            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+            const int xrow = ob >> 3, xhalf = (ob >> 2) & 1;
+            const int xcbl = xrow - half * CBC;                                 // my rows are chunk image `half`
+#pragma unroll
+            for (int j = 0; j < CTW; ++j) {
+                const int vv = (j0 + j) * 16 + ce;
+                if (vv >= v)
+                    continue;
+                char *q = xs + half * G::BYTES + (xcbl * G::VP + vv) * 16 + 8 * xhalf;
+                const h4 rh = *reinterpret_cast<const h4 *>(q);
+                const h4 rl = *reinterpret_cast<const h4 *>(q + G::PLANE);
+                h4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = relu_nan(acc[i2][j][i] * winv) * sc[i] + sh[i];
+                    x = fmaf((float)rh[i] + (float)rl[i], rmul, x);
+                    _Float16 xh, xl;
+                    dance::split_half(x, xh, xl);
+                    hi[i] = xh;
+                    lo[i] = xl;
+                }
+                *reinterpret_cast<h4 *>(q) = hi;
+                *reinterpret_cast<h4 *>(q + G::PLANE) = lo;
+                // device-scope (write-through) stores: the partner workgroup, possibly behind another L2,
+                // reads these words in a moment -- no cache-wide write-back fence is needed for them
+                unsigned long long *d = reinterpret_cast<unsigned long long *>(yslot + ((long long)xrow * v + vv) * 8 + 4 * xhalf);
+                __hip_atomic_store(d, __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d + 32ll * v, __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (l + 1 == a.nlayers)
+            break;
+        // ---- exchange: my half of slot l + 1 out, the partner's in.  Every store above has left this wave
+        // (vmcnt counts stores too) before the barrier; the flag goes out after it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                        // ... everybody's stores are out; the image rows I own are updated
+        if (t == 0) {
+            __hip_atomic_store(my_flag, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!gave_up) {
+                const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(partner_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < l + 1) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > COOP_WAIT_TICKS) {
+                        gave_up = 1;
+                        atomicOr(coop, 1);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // the partner's chunk image: rows (plane, channel block) of v 16-byte words, device-scope loads
+            const int pc = half ^ 1;
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(yslot);
+            constexpr int HB = CBC;                                         // channel blocks of a half = a chunk image
+            constexpr int PER = (2 * HB * RT * 32 + 511) / 512;             // 16-byte words per thread (4)
+            unsigned long long w8[PER][2];
+            // all loads first (they are independent round trips to the far side of the chip), then the LDS writes
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = min(t + 512 * k, 2 * HB * v - 1);
+                const int row = i / v, col = i - row * v;                   // row = plane * HB + block of the half
+                const int plane = row >= HB ? 1 : 0, cbl = row - plane * HB;
+                const unsigned long long *g = src + ((plane * 16ll + pc * HB + cbl) * v + col) * 2;
+                w8[k][0] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w8[k][1] = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = t + 512 * k;
+                if (i < 2 * HB * v) {
+                    const int row = i / v, col = i - row * v;
+                    const int plane = row >= HB ? 1 : 0, cbl = row - plane * HB;
+                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(
+                        xs + pc * G::BYTES + plane * G::PLANE + (cbl * G::VP + col) * 16);
+                    dst[0] = w8[k][0];
+                    dst[1] = w8[k][1];
+                }
+            }
+        }
+        __syncthreads();                        // image = block l + 1's input
+    }
+    if (gave_up) {
+        // never a finite wrong contour: my half of the last slot as NaN
+        _Float16 *ylast = sn + (long long)a.nlayers * a.slot;
+        const _Float16 qnan = __builtin_bit_cast(_Float16, (unsigned short)0x7e00);
+        for (int i = t; i < 8 * v * 8; i += 512) {
+            const int row = 8 * half + i / (v * 8), rest = i % (v * 8);
+            ylast[((long long)row * v) * 8 + rest] = qnan;
+        }
+    }
+}
+
 int pick_rt16(int v) { return v <= 64 ? 2 : (v <= 128 ? 4 : (v <= 224 ? 7 : 8)); }
 
 template <typename K>
@@ -534,7 +779,8 @@ extern "C" int dance_conv16(const void *x, int64_t x_stride, int64_t x_slot_stri
 }
 
 extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int64_t stride, int64_t slot,
-                                 int n, int v, int mfma_terms, const dance_policy *policy, void *stream)
+                                 int n, int v, int mfma_terms, const dance_policy *policy, int32_t *coop_scratch,
+                                 void *stream)
 {
     DANCE_REQUIRE(net != nullptr && n >= 0 && v >= 16 && v <= 256);
     DANCE_REQUIRE(mfma_terms == 3 || mfma_terms == 1);
@@ -561,7 +807,28 @@ extern "C" int dance_res_stack16(const dance_snake_net16 *net, void *state, int6
     // CU either way, so it gets 8 waves instead of 4 (-9 % on the stack at n = 100; same products
     // and summation order as k_res_stack16s, bit-identical): up to DANCE_FEW_STACK contours, unless
     // the policy switches the few-contour forms off.
-    const int small_n = dance::policy_or_default(policy).few_contour_forms ? DANCE_FEW_STACK : 0;
+    const dance_policy pol = dance::policy_or_default(policy);
+    const int small_n = pol.few_contour_forms ? DANCE_FEW_STACK : 0;
+    // still fewer (at most half the CUs): two workgroups, two CUs, per contour (k_res_stack16c)
+    if (rt == 4 && pol.few_contour_forms && pol.coop_stack && coop_scratch != nullptr && n <= DANCE_FEW_COOP &&
+        2 * n <= dance::cu_count()) {
+        if (int rc = dance::zero_async(coop_scratch, sizeof(int32_t) * (16 + 2 * (size_t)n), (hipStream_t)stream, __func__))
+            return rc;
+        const dim3 grid(16 * dance::ceil_div(n, 8));
+        int rc_ = 0;
+        if (mfma_terms == 1) {
+            rc_ = big_lds(k_res_stack16c<1>, lds, "dance_res_stack16");
+            if (!rc_)
+                hipLaunchKernelGGL((k_res_stack16c<1>), grid, dim3(512), lds, (hipStream_t)stream, a, n, coop_scratch);
+        } else {
+            rc_ = big_lds(k_res_stack16c<3>, lds, "dance_res_stack16");
+            if (!rc_)
+                hipLaunchKernelGGL((k_res_stack16c<3>), grid, dim3(512), lds, (hipStream_t)stream, a, n, coop_scratch);
+        }
+        if (rc_)
+            return rc_;
+        return launch_check(__func__);
+    }
     // an odd number of vertex tiles goes k + (k - 1) over the two groups of waves: 13 (193..208 vertices,
     // the shipped yamls' 196) as 7 + 6 instead of 14
     constexpr int odd_split = 1, mid = 1;

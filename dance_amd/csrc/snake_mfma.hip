@@ -652,7 +652,10 @@ int evolve16_after_head(const dance_snake_net16 *net, const Workspace &w, const 
     _Float16 *p1 = reinterpret_cast<_Float16 *>(w.p1);           // (n, 2 slots) P16
     const long long slot = 256ll * v, sstride = 8 * slot, pstride = 2 * slot;
     // one launch for the 7 residual blocks; its time is booked on stage res0
-    DANCE_TRY(dance_res_stack16(net, state, sstride, slot, n, v, mfma_terms, policy, stream));
+    // (the exact-fp32 path's gathered-input piece of the workspace is free here: the pair flags of the
+    // few-contour stack live in its first bytes)
+    DANCE_TRY(dance_res_stack16(net, state, sstride, slot, n, v, mfma_terms, policy, reinterpret_cast<int32_t *>(w.x0),
+                                stream));
     for (int i = 0; i < 7; ++i)
         DANCE_TRY(mark());
     // the fusion kernel (any ring length, rings above 128 vertices as two parts) + k_tail16 (parts' max,

@@ -44,10 +44,14 @@ typedef struct dance_policy {
     int few_contour_forms;
     int fuse_tail_split;
     int tail_group;
+    int coop_stack;     /* 1: with few_contour_forms, batches of at most DANCE_FEW_COOP contours (and at most half
+                           the CUs) run the residual stack on TWO workgroups per contour that exchange their
+                           halves through L2 after every block (dance_res_stack16); 0: never.  Bit-identical. */
 } dance_policy;
 #define DANCE_FEW_HEAD 128
 #define DANCE_FEW_STACK 256
 #define DANCE_FEW_FUSE 128
+#define DANCE_FEW_COOP 128
 
 /* ------------------------------------------------------- extreme_utils (L6) -------- */
 /* reference: core/layers/extreme_utils/src/utils.cu:114-212 (pybind `collect_extreme_point`,
@@ -613,9 +617,13 @@ typedef struct dance_snake_net16 {
  * gap instead of 7.  The ring runs ceil(v / 16) vertex tiles of 16 (at most one more): LDS images
  * of 64, 96, 128, 160, 192, 224 or 256 columns; above 128 vertices (and for 97..128 with few
  * contours, policy) 8 waves per contour with the tiles split over two groups of waves, odd counts as
- * k + (k - 1).  reference: _SnakeNet.forward snake_head.py:262-268. */
+ * k + (k - 1).  coop_scratch: 16 + 2 n int32 words of device scratch for the two-workgroup form of
+ * policy.coop_stack (zeroed here on the stream; word 0 = status, raised if a workgroup gave up waiting
+ * for its partner after 2 s -- that contour then comes out NaN), or NULL: that form is never used.
+ * reference: _SnakeNet.forward snake_head.py:262-268. */
 int dance_res_stack16(const dance_snake_net16 *net_host, void *state, int64_t stride, int64_t slot,
-                      int n, int v, int mfma_terms, const dance_policy *policy, void *stream);
+                      int n, int v, int mfma_terms, const dance_policy *policy, int32_t *coop_scratch,
+                      void *stream);
 
 /* dance_snake_evolve in the fast precision mode (same workspace size, same stage events):
  * dance_gather_head16w -> dance_res_stack16 -> dance_fuse16w_raw(_split) -> dance_tail16.

@@ -300,7 +300,7 @@ def test_res_stack_vs_single_blocks_and_torch(device, v):
         b = a.clone()
         with torch.cuda.device(device):
             st = current_stream()
-            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(a), a.stride(0), slot, n, v, terms, None, st), "stack")
+            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(a), a.stride(0), slot, n, v, terms, None, None, st), "stack")
             for i in range(7):
                 check(lib().dance_conv16(ptr(b[:, i]), b.stride(0), slot, s16.res_w[i], s16.res_bs[i],
                                          s16.res_winv[i], s16.res_scale[i], s16.res_shift[i], None, 1, 1, 0,
@@ -326,11 +326,26 @@ def test_res_stack_vs_single_blocks_and_torch(device, v):
         c[:, 0] = ops.to_p16((x * sc0).to(device))[:, 0]
         e = c.clone()
         with torch.cuda.device(device):
-            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(c), c.stride(0), slot, 37, v, 3, None,
+            check(lib().dance_res_stack16(ctypes.byref(s16), ptr(c), c.stride(0), slot, 37, v, 3, None, None,
                                           current_stream()), "stack")
             check(lib().dance_res_stack16(ctypes.byref(s16), ptr(e), e.stride(0), slot, 37, v, 3,
-                                          ctypes.byref(PolicyStruct(few_contour_forms=0)), current_stream()), "stack")
+                                          ctypes.byref(PolicyStruct(few_contour_forms=0)), None, current_stream()), "stack")
         assert torch.equal(c.view(torch.int16), e.view(torch.int16))
+        # and the two-workgroups-per-contour form (policy.coop_stack, given its scratch words): a contour's
+        # output channels on two CUs, halves exchanged through L2 after every block -- identical bits, status 0
+        for n, terms in ((1, 3), (37, 3), (100, 3), (128, 1), (9, 3)):
+            x = torch.randn((n, 128, v), generator=torch.Generator().manual_seed(v + n)) * 2
+            c = torch.zeros((n, 8, 2, 16, v, 8), dtype=torch.float16, device=device)
+            c[:, 0] = ops.to_p16((x * sc0).to(device))[:, 0]
+            e = c.clone()
+            scratch = torch.full((16 + 2 * n,), 7, dtype=torch.int32, device=device)
+            with torch.cuda.device(device):
+                check(lib().dance_res_stack16(ctypes.byref(s16), ptr(c), c.stride(0), slot, n, v, terms, None, ptr(scratch),
+                                              current_stream()), "stack")
+                check(lib().dance_res_stack16(ctypes.byref(s16), ptr(e), e.stride(0), slot, n, v, terms, None, None,
+                                              current_stream()), "stack")
+            assert torch.equal(c.view(torch.int16), e.view(torch.int16)), (v, n, terms)
+            assert int(scratch[0]) == 0 and scratch[16:].tolist() == [6] * (2 * n)
 
 
 def test_deformation_replays_from_a_hip_graph(device):
