@@ -69,6 +69,14 @@ class GraphedEdgeSnakeFPNHead:
         self._graphs[key] = e
         return e
 
+    def input_buffers(self, features, image_size):
+        """The graph's static feature buffers for this input signature (captured on first use from
+        `features`): a backbone that writes its pyramid levels into these tensors and passes them to
+        __call__ saves the per-call copy (82 MB, ~0.1 ms, for an 800x1216 image)."""
+        key = (tuple(image_size),) + tuple((f, tuple(features[f].shape)) for f in self.head.in_features)
+        e = self._graphs.get(key) or self._capture(key, features, image_size)
+        return e["feats"]
+
     def __call__(self, features, boxes, image_size):
         n = int(boxes.shape[0])
         if n > self.k:
@@ -78,7 +86,8 @@ class GraphedEdgeSnakeFPNHead:
         if e is None:
             e = self._capture(key, features, image_size)
         for f in self.head.in_features:
-            e["feats"][f].copy_(features[f])
+            if features[f].data_ptr() != e["feats"][f].data_ptr():      # (a producer may write into input_buffers() directly)
+                e["feats"][f].copy_(features[f])
         if n:
             e["boxes_in"][:n].copy_(boxes)
         if n < self.k:

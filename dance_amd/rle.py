@@ -32,6 +32,14 @@ def _as_polys(polygons):
     return polygons.contiguous()
 
 
+class _CapacityExceeded(Exception):
+    """an instance has more runs than the slots it was given (deferred check)"""
+
+    def __init__(self, need):
+        super().__init__(need)
+        self.need = int(need)
+
+
 class PolygonRLE:
     """Run lengths of N masks on the device.
 
@@ -46,8 +54,8 @@ class PolygonRLE:
         return self.counts.size(0)
 
     def strings(self):
-        """list of N `bytes`: pycocotools' compressed "counts" (rleToString).  One device ->
-        host copy of the packed bytes."""
+        """list of N `bytes`: pycocotools' compressed "counts" (rleToString).  Two host round trips:
+        the packed sizes (with the run counts of a deferred capacity check), then the packed bytes."""
         n, cap = self.counts.shape
         if n == 0:
             return []
@@ -56,14 +64,18 @@ class PolygonRLE:
         with torch.cuda.device(dev):
             check(lib().dance_rle_to_string(ptr(self.counts), ptr(self.m), n, cap, None, None, 0, ptr(lens),
                                             current_stream()), "rle_to_string")
-            offsets = torch.zeros((n + 1,), dtype=torch.int64, device=dev)
-            torch.cumsum(lens, 0, out=offsets[1:])
-            total = int(offsets[-1])             # the copy below needs the size anyway
+            offsets = torch.zeros((n + 2,), dtype=torch.int64, device=dev)
+            torch.cumsum(lens, 0, out=offsets[1:n + 1])
+            offsets[n + 1] = self.m.max()        # rides along: one copy instead of two
+            off = offsets.cpu().tolist()
+            need = off.pop()
+            if need > cap:                       # (only reachable with the capacity check deferred)
+                raise _CapacityExceeded(need)
+            total = off[-1]
             packed = torch.empty((max(total, 1),), dtype=torch.uint8, device=dev)
             check(lib().dance_rle_to_string(ptr(self.counts), ptr(self.m), n, cap, ptr(packed), ptr(offsets),
                                             total, ptr(lens), current_stream()), "rle_to_string")
         raw = packed.cpu().numpy().tobytes()
-        off = offsets.cpu().tolist()
         return [raw[off[i]:off[i + 1]] for i in range(n)]
 
     def to_coco(self):
@@ -84,12 +96,13 @@ class PolygonRLE:
         return mask.transpose(1, 2)
 
 
-def polygon_rle(polygons, image_shape, cap=None):
+def polygon_rle(polygons, image_shape, cap=None, defer_check=False):
     """frPyObjects + merge for N single-polygon instances: polygons (N,V,2) or (N,2V) float32
     on the GPU, image_shape (h, w) -> PolygonRLE.  `cap` = run slots per instance (default
     2*w + 2, enough for any polygon that crosses each column at most twice); if an instance
     needs more the call is repeated once with the exact maximum (this check synchronises, as
-    the reference's host copy does)."""
+    the reference's host copy does).  defer_check: no synchronisation here; `strings()` looks at the run
+    counts with its first host copy and raises _CapacityExceeded (get_polygon_rles repeats the call)."""
     polys = _as_polys(polygons)
     h, w = int(image_shape[0]), int(image_shape[1])
     if h < 1 or w < 1 or h > 327680 or h * w >= 2 ** 31:
@@ -106,6 +119,8 @@ def polygon_rle(polygons, image_shape, cap=None):
         with torch.cuda.device(dev):
             check(lib().dance_polygon_rle(ptr(polys), None, n, v, h, w, ptr(counts), cap, ptr(m), ptr(area),
                                           None, current_stream()), "polygon_rle")
+        if defer_check:
+            break
         need = int(m.max())
         if need <= cap:
             break
@@ -117,4 +132,7 @@ def get_polygon_rles(polygons, image_shape):
     """Drop-in for the reference's function of the same name (coco_evaluation.py:311-318):
     polygons N x (p*2) (a GPU tensor here -- no `.cpu()` of the contours), image_shape (h, w)
     -> list of {"size": [h, w], "counts": bytes}."""
-    return polygon_rle(polygons, image_shape).to_coco()
+    try:
+        return polygon_rle(polygons, image_shape, defer_check=True).to_coco()
+    except _CapacityExceeded as e:
+        return polygon_rle(polygons, image_shape, cap=e.need).to_coco()
