@@ -73,3 +73,30 @@ def test_static_scratch_nms_rejects_lists_beyond_its_array(device):
     count = torch.zeros((1,), dtype=torch.int32, device=device)
     rc = fn(rows.data_ptr(), STATIC_MAX + 1, 0.6, keep.data_ptr(), count.data_ptr(), None)
     assert rc == 1 and b"static scratch" in h.dance_last_error()
+
+
+def test_static_scratch_nms_inside_a_hip_graph(device):
+    """What the entry point is for: a caller under stream capture.  After one warm-up call outside the
+    capture (the header's rule: the first call on a device looks the array's address up), the call is
+    captured into a HIP graph -- nothing in it allocates or synchronises, or the capture would fail --
+    and the replays, on new box coordinates written into the same input buffer and an empty list via the
+    n = 0 path, give what the workspace form gives."""
+    h, fn = _bind()
+    n = 900
+    rows = _sorted_rows(n, 11, device)
+    _static(fn, rows, 0.6)                                    # warm-up outside the capture
+    torch.cuda.synchronize()
+    keep = torch.full((n,), -1, dtype=torch.int64, device=device)
+    count = torch.full((1,), -1, dtype=torch.int32, device=device)
+    from dance_amd._lib import check, current_stream, ptr
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        check(fn(ptr(rows), n, 0.6, ptr(keep), ptr(count), current_stream()), "nms_static (captured)")
+    for seed in (11, 12, 13):
+        rows.copy_(_sorted_rows(n, seed, device))             # same buffer, new boxes
+        k0, c0 = _with_workspace(h, rows, 0.6)
+        _static(fn, _sorted_rows(300, seed + 50, device), 0.6)   # an eager call in between: the array is shared
+        g.replay()
+        torch.cuda.synchronize()
+        m = int(c0.item())
+        assert int(count.item()) == m and torch.equal(keep[:m], k0[:m])
