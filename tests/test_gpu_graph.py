@@ -3,6 +3,8 @@ forward for the real detections, for changing inputs and detection counts on the
 to the bit: nothing on the path sums in an order that varies (the feature-prep layers' GroupNorm
 statistics are per-workgroup partials folded in a fixed order, csrc/common.h k_sum_rows), so two
 eager forwards are identical too (SURVEY section 5's run-twice check)."""
+import os
+
 import pytest
 import torch
 
@@ -11,6 +13,18 @@ from dance_amd import graph, modules, synthetic
 from dance_amd.structures import Boxes, Instances
 
 pytestmark = pytest.mark.gpu
+
+# the opt-out knobs put torch's GroupNorm / convolutions in front of the deformer: those sum
+# in an order that varies, so under them eager-twice and graph-vs-eager hold to a tolerance, not to the bit
+HIP_FEATPREP = (os.environ.get("DANCE_FEATPREP", "hip") == "hip"
+                and os.environ.get("DANCE_PRECISION", "fp16x3") == "fp16x3")
+
+
+def _same(a, b):
+    if HIP_FEATPREP:
+        return torch.equal(a.view(torch.int32), b.view(torch.int32))
+    nan_a, nan_b = torch.isnan(a), torch.isnan(b)
+    return torch.equal(nan_a, nan_b) and float((a - b)[~nan_a].abs().max()) <= 5e-3
 
 
 def test_graphed_head_equals_eager(device):
@@ -37,10 +51,10 @@ def test_graphed_head_equals_eager(device):
         want, want2 = res[0].pred_polys.tensor, res2[0].pred_polys.tensor
         # run twice, compare bits: attention map and contours (a box clipped to zero width is a NaN contour
         # in the reference and here -- derange -- at the same places)
-        assert torch.equal(att_e, att_e2)
-        assert torch.equal(want.view(torch.int32), want2.view(torch.int32))
+        assert _same(att_e, att_e2)
+        assert _same(want, want2)
         # and the graph replays exactly what eager computes
-        assert torch.equal(att_g, att_e)
-        assert torch.equal(polys_g.view(torch.int32), want.view(torch.int32))
+        assert _same(att_g, att_e)
+        assert _same(polys_g, want)
         assert bool(torch.isfinite(polys_g).any())
     assert len(g._graphs) == 1

@@ -10,6 +10,8 @@ AND 0.02 px against the fp32 oracle run on the SAME rescaled weights and feature
 rescaling is an exact invariance of the fp32 network the oracle's own result is also checked
 to be unchanged.  Beyond the representable range the result must be NaN (loud), never a finite
 wrong number.  reference arithmetic: fp32 throughout, snake_head.py:92-153, 220-284."""
+import os
+
 import pytest
 import torch
 
@@ -234,6 +236,8 @@ def test_dsnake_feature_scale(device, k):
     head.load_state_dict(sd)
     head = head.to(device).eval()
     d = head._get_deformer()
+    if os.environ.get("DANCE_PRECISION", "fp16x3") != "fp16x3":
+        pytest.skip("the module follows DANCE_PRECISION; this test is about the fast mode's range")
     assert d.precision == "fp16x3"
     nhwc, _ = ops.nchw_to_nhwc(feats.to(device), 0)
     idx = want["image_idx"].to(torch.int32).to(device)
