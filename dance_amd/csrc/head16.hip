@@ -19,6 +19,22 @@
 
 using dance::launch_check;
 
+#ifdef DANCE_EXP_STAMPS
+// experiment build only (tools/build_variant.py): phase time stamps of k_gather_head16w, 100 MHz real-time clock
+__device__ unsigned long long g_head_stamps[2048][16];
+extern "C" int dance_exp_head_stamps(void *dst)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_head_stamps), sizeof(g_head_stamps));
+}
+#define STAMP(i)                                                                                      \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 2048)                                                    \
+            g_head_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime();                          \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 struct Head16Args {
@@ -63,7 +79,37 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
     const bool img_ok = img >= 0 && img < a.b;
     img = img_ok ? img : 0;
     const long long plane = (long long)a.hf * a.wf;
+#ifdef DANCE_EXP_HEAD
+    {
+        // experiment: break the symmetry between the workgroups that share a CU
+        unsigned slot;
+        if (DANCE_EXP_HEAD & 1)
+            slot = (__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4)) % 3u;     // HW_ID.TG_ID
+        else
+            slot = (unsigned)(blockIdx.x / 256) % 3u;
+        if (DANCE_EXP_HEAD & 2) {
+            if (slot == 0)
+                __builtin_amdgcn_s_setprio(3);
+            else if (slot == 1)
+                __builtin_amdgcn_s_setprio(2);
+            else
+                __builtin_amdgcn_s_setprio(1);
+        }
+        if (DANCE_EXP_HEAD & 4) {
+            if (blockIdx.x < 768)
+                for (unsigned i = 0; i < slot * DANCE_EXP_STAGGER; ++i)
+                    __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
 
+    STAMP(0);
+#ifdef DANCE_EXP_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {
+        g_head_stamps[blockIdx.x][14] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_ID
+        g_head_stamps[blockIdx.x][15] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // XCC_ID
+    }
+#endif
     float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
     if (a.deloc != DANCE_DELOC_NONE)
         dance::contour_bounds(loc_n, v, red, xmin, xmax, ymin, ymax);
@@ -161,8 +207,10 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
     const float *fimg = a.feat + img * plane * a.c;
     const int lc = t & 15, vs = t >> 4;                         // 16 lanes x float4 = 64 channels
     auto nohook = [](int) __attribute__((always_inline)) {};
+    STAMP(1);
     for (int c0 = 0; c0 < a.c; c0 += 64) {
         __syncthreads();
+        STAMP(2 + (c0 >> 6) * 3);
 #pragma unroll 4
         for (int s = vs; s < v; s += 16) {
 #pragma clang fp contract(off)
@@ -189,7 +237,9 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
             *reinterpret_cast<h4 *>(d) = hi;
             *reinterpret_cast<h4 *>(d + G::PLANE) = lo;
         }
+        STAMP(3 + (c0 >> 6) * 3);
         __syncthreads();
+        STAMP(4 + (c0 >> 6) * 3);
         mfma16_core_sw<RTG, CT, NST, AD, NB, TERMS>(acc, xs, 0, v,
                                                     reinterpret_cast<const char *>(a.w) + ((long long)(c0 >> 3) * 128 + o0) * 16,
                                                     wlane, wps_b, wts_b, 4 * wbs_b, 9, 1, c16, q4, 0, nohook);
@@ -216,6 +266,7 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
             dance::store_p16(yslot, v, ob >> 3, vv, (ob >> 2) & 1, val);
         }
     }
+    STAMP(13);
 }
 
 template <int RTG, int CT>
