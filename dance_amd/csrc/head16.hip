@@ -21,7 +21,7 @@ using dance::launch_check;
 
 #ifdef DANCE_EXP_STAMPS
 // experiment build only (tools/build_variant.py): phase time stamps of k_gather_head16w, 100 MHz real-time clock
-__device__ unsigned long long g_head_stamps[2048][16];
+__device__ unsigned long long g_head_stamps[2048][20];
 extern "C" int dance_exp_head_stamps(void *dst)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_head_stamps), sizeof(g_head_stamps));
@@ -79,35 +79,12 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
     const bool img_ok = img >= 0 && img < a.b;
     img = img_ok ? img : 0;
     const long long plane = (long long)a.hf * a.wf;
-#ifdef DANCE_EXP_HEAD
-    {
-        // experiment: break the symmetry between the workgroups that share a CU
-        unsigned slot;
-        if (DANCE_EXP_HEAD & 1)
-            slot = (__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4)) % 3u;     // HW_ID.TG_ID
-        else
-            slot = (unsigned)(blockIdx.x / 256) % 3u;
-        if (DANCE_EXP_HEAD & 2) {
-            if (slot == 0)
-                __builtin_amdgcn_s_setprio(3);
-            else if (slot == 1)
-                __builtin_amdgcn_s_setprio(2);
-            else
-                __builtin_amdgcn_s_setprio(1);
-        }
-        if (DANCE_EXP_HEAD & 4) {
-            if (blockIdx.x < 768)
-                for (unsigned i = 0; i < slot * DANCE_EXP_STAGGER; ++i)
-                    __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#endif
 
     STAMP(0);
 #ifdef DANCE_EXP_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 2048) {
-        g_head_stamps[blockIdx.x][14] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_ID
-        g_head_stamps[blockIdx.x][15] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // XCC_ID
+        g_head_stamps[blockIdx.x][17] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_ID
+        g_head_stamps[blockIdx.x][18] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // XCC_ID
     }
 #endif
     float xmin = 0.f, xmax = 0.f, ymin = 0.f, ymax = 0.f;
@@ -266,7 +243,7 @@ __global__ __launch_bounds__(256, MINB) void k_gather_head16w(Head16Args a)
             dance::store_p16(yslot, v, ob >> 3, vv, (ob >> 2) & 1, val);
         }
     }
-    STAMP(13);
+    STAMP(16);
 }
 
 template <int RTG, int CT>

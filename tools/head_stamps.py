@@ -50,16 +50,16 @@ torch.cuda.synchronize()
 print("head kernel: %.4f ms per launch" % (e0.elapsed_time(e1) / 20))
 if not hasattr(lib(), "dance_exp_head_stamps"):
     sys.exit(0)
-buf = np.zeros((2048, 16), dtype=np.uint64)
+buf = np.zeros((2048, 20), dtype=np.uint64)
 lib().dance_exp_head_stamps.argtypes = [ctypes.c_void_p]
 assert lib().dance_exp_head_stamps(buf.ctypes.data) == 0
 st = buf[:N].astype(np.int64)
 t0 = st[:, 0].min()
-us = (st[:, :14] - t0) / 100.0                     # 100 MHz -> us
-hw, xcc = st[:, 14], st[:, 15]
+us = (st[:, :17] - t0) / 100.0                     # 100 MHz -> us
+hw, xcc = st[:, 17], st[:, 18]
 cu = ((xcc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
 tg = (hw >> 16) & 15
-print("kernel span %.1f us; distinct CUs %d; TG_ID values %s" % (us[:, 13].max(), len(set(cu.tolist())), sorted(set(tg.tolist()))))
+print("kernel span %.1f us; distinct CUs %d; TG_ID values %s" % (us[:, 16].max(), len(set(cu.tolist())), sorted(set(tg.tolist()))))
 first = us[:, 0] < 5.0
 print("workgroups starting in the first 5 us: %d" % first.sum())
 
@@ -77,14 +77,14 @@ for sel, tag in ((first, "first round"), (~first, "later rounds")):
     for c in range(4):
         stats("chunk %d gather (wave 0)" % c, u[:, 3 + 3 * c] - u[:, 2 + 3 * c])
         stats("chunk %d wait for the other waves" % c, u[:, 4 + 3 * c] - u[:, 3 + 3 * c])
-        nxt = u[:, 2 + 3 * (c + 1)] if c < 3 else u[:, 13]
+        nxt = u[:, 2 + 3 * (c + 1)] if c < 3 else u[:, 16]
         stats("chunk %d MFMA (+ barrier / epilogue)" % c, nxt - u[:, 4 + 3 * c])
-    stats("whole workgroup", u[:, 13] - u[:, 0])
+    stats("whole workgroup", u[:, 16] - u[:, 0])
 # how synchronised are the phases chip-wide: at sampled times, the share of live workgroups inside a gather phase
-ts = np.arange(0.0, us[:, 13].max(), 2.0)
+ts = np.arange(0.0, us[:, 16].max(), 2.0)
 share = []
 for t in ts:
-    live = (us[:, 0] <= t) & (us[:, 13] > t)
+    live = (us[:, 0] <= t) & (us[:, 16] > t)
     ing = np.zeros(N, dtype=bool)
     for c in range(4):
         ing |= (us[:, 2 + 3 * c] <= t) & (us[:, 4 + 3 * c] > t)
@@ -93,4 +93,4 @@ print("t(us): live workgroups / of them gathering")
 print(" ".join("%d:%d/%d" % (t, a, b) for t, (a, b) in zip(ts, share)))
 # per-CU: order of one CU's workgroups
 one = cu == cu[0]
-print("workgroups of CU %#x: " % cu[0], [(int(i), int(tg[i]), round(float(us[i, 0]), 1), round(float(us[i, 13]), 1)) for i in np.nonzero(one)[0]])
+print("workgroups of CU %#x: " % cu[0], [(int(i), int(tg[i]), round(float(us[i, 0]), 1), round(float(us[i, 16]), 1)) for i in np.nonzero(one)[0]])
