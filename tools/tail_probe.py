@@ -1,4 +1,4 @@
-"""Determinism probe of dance_fuse16_raw + dance_tail16 at sizes where workgroups start late
+"""Determinism probe of dance_fuse16w_raw + dance_tail16 at sizes where workgroups start late
 (more workgroups than the CUs hold at once): reruns must be bit-identical.  PYTHONPATH=. """
 import sys
 import torch
@@ -12,7 +12,7 @@ cfg, sd, _ = dance_state_dict(1234, 128)
 net = snake.SnakeNetWeights(snake.sub_state_dict(sd, "deformer0."), device)
 for v in (128, 196):
     n = 3200
-    x, state, loc, whs, att = T._inputs(n, v, device, 1)
+    state, loc, whs, att = T._inputs(net, n, v, device, 1)
     outs = [T._fused(net.struct16, state, loc, whs, att, n, v, 3, False)[1] for _ in range(4)]
     torch.cuda.synchronize()
     print(v, "reruns identical:", all(torch.equal(outs[0], o) for o in outs[1:]))
