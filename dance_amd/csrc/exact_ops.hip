@@ -613,6 +613,9 @@ struct RsExtremes {
     long long poly_stride, point_stride; // floats between instances / between the 4 points in src
 };
 
+#ifdef DANCE_EXP_LERP
+__attribute__((target("packed-fp32-ops")))          // the experiment's asm needs the feature the build switches off
+#endif
 __global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *__restrict__ src,
                                                          int E, int p_num, float *__restrict__ out,
                                                          long long *__restrict__ start_out,
@@ -776,10 +779,44 @@ __global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *
         const int nx = e + 1 == E ? 0 : e + 1;
         const float wgt = (float)(s - (int)start[e]) / (float)cnt[e];
         const float om = 1.0f - wgt;
+#if defined(DANCE_EXP_LERP) && DANCE_EXP_LERP != 5     // 5: plain source, the compiler's own packed forms
+        // experiment build only (tools/build_variant.py): the lerp in the packed fp32 forms hipcc chose before the
+        // library was built without them, written out so that one ingredient at a time can change.
+        //   1: as compiled then -- second product with the {wgt, om} pair as BOTH source (halves swapped through
+        //      op_sel) and destination;  2: the same with a destination of its own;  3: no op_sel (the pair
+        //      swapped by moves first), destination = source pair;  4: as 1 with 8 idle cycles around each packed op
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 t2 = {wgt, om}, a2 = {px[nx], py[e]}, b2 = {px[e], py[nx]}, r2;
+#if DANCE_EXP_LERP == 1
+        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));
+        asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]" : "+v"(t2) : "v"(b2));
+        asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(t2) : "v"(a2));
+        r2 = t2;
+#elif DANCE_EXP_LERP == 2
+        f2 m2;
+        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(m2) : "v"(b2), "v"(t2));
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=&v"(r2) : "v"(a2), "v"(m2));
+#elif DANCE_EXP_LERP == 3
+        f2 sw = {om, wgt};
+        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));
+        asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(sw) : "v"(b2));
+        asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(sw) : "v"(a2));
+        r2 = sw;
+#else
+        asm volatile("s_nop 7\n\tv_pk_mul_f32 %0, %0, %1\n\ts_nop 7" : "+v"(a2) : "v"(t2));
+        asm volatile("v_pk_mul_f32 %0, %1, %0 op_sel:[0,1] op_sel_hi:[1,0]\n\ts_nop 7" : "+v"(t2) : "v"(b2));
+        asm volatile("v_pk_add_f32 %0, %1, %0\n\ts_nop 7" : "+v"(t2) : "v"(a2));
+        r2 = t2;
+#endif
+        o[s * 2] = r2.x;
+        o[s * 2 + 1] = r2.y;
+#else
         const float x = px[e] * om, x2 = px[nx] * wgt;
         const float y = py[e] * om, y2 = py[nx] * wgt;
         o[s * 2] = x + x2;
         o[s * 2 + 1] = y + y2;
+#endif
     }
 }
 

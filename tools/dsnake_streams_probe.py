@@ -29,6 +29,7 @@ def run(streams):
 
 
 ref = run(1)
+print("library:", os.environ.get("DANCE_HIP_LIB", "in-tree"), flush=True)
 for trial in range(3):
     for k in (1, 2):
         got = run(k)
@@ -38,6 +39,14 @@ for trial in range(3):
             if len(bad):
                 print("trial %d streams %d %s: %d contours differ, max %.3e, first %s" % (
                     trial, k, name, len(bad), float(d.max()), bad[:8].tolist()))
+                if got[name].dim() == 3 and got[name].shape[1] % 64 == 0:
+                    # which vertices: (pass = vertex // 64, lane quarter = vertex % 64 // 16) -> count
+                    vd = ((got[name] - ref[name]).abs().amax(dim=2) != 0).nonzero()[:, 1]
+                    hist = {}
+                    for v in vd.tolist():
+                        key = (v // 64, v % 64 // 16)
+                        hist[key] = hist.get(key, 0) + 1
+                    print("    differing vertices by (pass, lane quarter):", sorted(hist.items()))
                 if name == "octagons" and trial == 0:
                     i = int(bad[0])
                     print(" exts ref", ref["exts"][i].flatten().tolist())
