@@ -797,6 +797,20 @@ __global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *
         asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));
         asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(m2) : "v"(b2), "v"(t2));
         asm volatile("v_pk_add_f32 %0, %1, %2" : "=&v"(r2) : "v"(a2), "v"(m2));
+#elif DANCE_EXP_LERP == 6
+        // op_sel on source 0 instead of source 1: b2 arrives swapped, {py[nx], px[e]}, and is swapped back by op_sel
+        f2 bs = {b2.y, b2.x}, m2;
+        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));
+        f2 ts = {om, wgt};
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(m2) : "v"(bs), "v"(ts));
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=&v"(r2) : "v"(a2), "v"(m2));
+#elif DANCE_EXP_LERP == 7
+        // only the HIGH result selects a non-default half (a broadcast of source 1's low half, the form of the first
+        // sighting's GEMV): lo = px[e] * om, hi = py[nx] * wgt computed as {b2.x, b2.y} * {om, om} and {.., wgt} apart
+        f2 m2, oo = {om, wgt}, ww = {wgt, om}, c2 = {px[e], py[e]}, d2 = {px[nx], py[nx]};
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(m2) : "v"(c2), "v"(oo));       // {px[e] om, py[e] om}
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(a2) : "v"(d2), "v"(ww));       // {px[nx] wgt, py[nx] wgt}
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=&v"(r2) : "v"(m2), "v"(a2));
 #elif DANCE_EXP_LERP == 3
         f2 sw = {om, wgt};
         asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));

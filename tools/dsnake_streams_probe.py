@@ -47,6 +47,13 @@ for trial in range(3):
                         key = (v // 64, v % 64 // 16)
                         hist[key] = hist.get(key, 0) + 1
                     print("    differing vertices by (pass, lane quarter):", sorted(hist.items()))
+                    if name == "octagons":
+                        ne = (got[name] != ref[name])
+                        print("    differing x / y coordinates: %d / %d" % (int(ne[..., 0].sum()), int(ne[..., 1].sum())))
+                        i, v = [int(t) for t in ne[..., 0].nonzero()[0]] if int(ne[..., 0].sum()) else (int(bad[0]), 0)
+                        print("    e.g. contour %d vertex %d: got %s want %s, neighbours want %s %s" % (
+                            i, v, got[name][i, v].tolist(), ref[name][i, v].tolist(), ref[name][i, v - 1].tolist(),
+                            ref[name][i, (v + 1) % ref[name].shape[1]].tolist()))
                 if name == "octagons" and trial == 0:
                     i = int(bad[0])
                     print(" exts ref", ref["exts"][i].flatten().tolist())
