@@ -8,7 +8,8 @@ from _util import FakeBoxes, FakeInstances
 from dance_amd import config, modules, synthetic
 dev = torch.device('cuda')
 b, per, HF, WF = 32, 100, 200, 304
-for nc in (0, 2):
+only = os.environ.get("DSNAKE_BENCH_ONLY")
+for nc in ((0, 2) if only is None else (int(only),)):
     cfg = config.dsnake_r50(num_convs=nc)
     head = modules.DsnakeHead(cfg)
     sd = {k: v.clone() for k, v in head.state_dict().items()}
@@ -25,8 +26,9 @@ for nc in (0, 2):
         run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    reps = int(os.environ.get("DSNAKE_BENCH_REPS", "5"))
+    for _ in range(reps):
         run()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 5 * 1e3
+    ms = (time.perf_counter() - t0) / reps * 1e3
     print("DsnakeHead NUM_CONVS=%d: %.2f ms per forward, %.0f contours/s" % (nc, ms, b * per / ms * 1e3))
