@@ -1,5 +1,5 @@
 """Build an experimental variant of libdance_hip.so for same-box A/Bs (tools/ab_variants.sh):
-    python tools/build_variant.py <name> <source.hip> [-DMACRO=VALUE ...]
+    python tools/build_variant.py <name> <source.hip | all> [-DMACRO=VALUE ...] [--allow-packed]
 recompiles ONE translation unit with the extra defines and links it with the in-tree objects of the
 others into dance_amd/_variants/lib_<name>.so (git-ignored, travels to the GPU box)."""
 import os
@@ -14,10 +14,15 @@ name, src, defs = sys.argv[1], sys.argv[2], [a for a in sys.argv[3:] if a != "--
 B.build()
 vdir = os.path.join(B.HERE, "_variants")
 os.makedirs(vdir, exist_ok=True)
-extra = dict(B.SOURCES)[src]
-obj = os.path.join(vdir, "%s_%s.o" % (name, src.replace(".hip", "")))
-B._compile(["/opt/rocm/bin/hipcc", "-x", "hip"] + B.COMMON + extra + defs + ["-c", os.path.join(B.CSRC, src), "-o", obj])
-objs = [obj if s == src else os.path.join(B.OBJ, s.replace(".hip", ".o")) for s, _ in B.SOURCES]
+srcs = [x for x, _ in B.SOURCES] if src == "all" else [src]
+objs = []
+for s_, extra in B.SOURCES:
+    if s_ in srcs:
+        obj = os.path.join(vdir, "%s_%s.o" % (name, s_.replace(".hip", "")))
+        B._compile(["/opt/rocm/bin/hipcc", "-x", "hip"] + B.COMMON + extra + defs + ["-c", os.path.join(B.CSRC, s_), "-o", obj])
+        objs.append(obj)
+    else:
+        objs.append(os.path.join(B.OBJ, s_.replace(".hip", ".o")))
 out = os.path.join(vdir, "lib_%s.so" % name)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=" + B.ARCH, "-shared", "-fPIC", "-o", out] + objs)
 if "--allow-packed" not in sys.argv:
