@@ -811,6 +811,13 @@ __global__ __launch_bounds__(64) void k_uniform_upsample(int kind, const float *
         asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(m2) : "v"(c2), "v"(oo));       // {px[e] om, py[e] om}
         asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(a2) : "v"(d2), "v"(ww));       // {px[nx] wgt, py[nx] wgt}
         asm volatile("v_pk_add_f32 %0, %1, %2" : "=&v"(r2) : "v"(m2), "v"(a2));
+#elif DANCE_EXP_LERP == 8
+        // ONLY the low result re-selects: lo = c2.lo * t2.HI, hi = c2.hi * t2.hi (op_sel:[0,1], op_sel_hi default);
+        // the other product broadcasts t2's LOW half to the high result (the form build 7 showed clean)
+        f2 m2, c2 = {px[e], py[e]}, d2 = {px[nx], py[nx]};
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(m2) : "v"(c2), "v"(t2));          // {px[e] om, py[e] om}
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(a2) : "v"(d2), "v"(t2));       // {px[nx] wgt, py[nx] wgt}
+        asm volatile("v_pk_add_f32 %0, %1, %2" : "=&v"(r2) : "v"(m2), "v"(a2));
 #elif DANCE_EXP_LERP == 3
         f2 sw = {om, wgt};
         asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(t2));
