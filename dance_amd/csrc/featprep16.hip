@@ -248,12 +248,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_16(Conv2dArgs a)
             if constexpr (q + 3 < 72)
                 C2_LOAD_B(q + 3);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tap % 3][0], bh[q % 4], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tap % 3][1], bh[q % 4], acc[1][j], 0, 0, 0);
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][0], bl[q % 4], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][1], bl[q % 4], acc[1][j], 0, 0, 0);
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][0], bh[q % 4], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][1], bh[q % 4], acc[1][j], 0, 0, 0);
+            // an accumulator tile's three products back to back (mfma16.h, mfma16_core_sw)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tap % 3][i], bh[q % 4], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][i], bl[q % 4], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tap % 3][i], bh[q % 4], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
 #undef C2_LOAD_B
         // the other buffer was last read for chunk - 1, which every wave left before the

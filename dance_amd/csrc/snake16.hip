@@ -523,16 +523,16 @@ __device__ __forceinline__ void coop_core(f32x4 (&acc)[2][2], const char *xs, un
             COOP_LOAD_B(g + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            if constexpr (TERMS == 3) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g % AD][0], bh[g % 2][j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g % AD][1], bh[g % 2][j], acc[1][j], 0, 0, 0);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][0], bl[g % 2][j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][1], bl[g % 2][j], acc[1][j], 0, 0, 0);
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {               // an accumulator tile's three products back to back (mfma16.h)
+                if constexpr (TERMS == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g % AD][i], bh[g % 2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][i], bl[g % 2][j], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][i], bh[g % 2][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][0], bh[g % 2][j], acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g % AD][1], bh[g % 2][j], acc[1][j], 0, 0, 0);
-        }
     });
 #undef COOP_LOAD_A
 #undef COOP_LOAD_B
